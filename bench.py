@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- encode throughput of the FELICS GPU path on synthetic 4K 8-bit grayscale frames.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the whole encode path (felics_compress_batch_device) over one batch of
+FRAMES synthetic S1 frames that are already resident in HBM; the .felics
+streams end up in HBM too.  Frames are independent streams, so ranks shard them with no data-path
+collective (weak scaling: every rank encodes its own FRAMES frames); torch.distributed is used for
+the barrier and the max-over-ranks time only.
+
+Rank 0 prints one JSON line: MPix/s over all ranks, the HBM-read roofline of the dominant kernel
+(HIP events on the library's own stream, averaged over the timed steps) and the CPU baseline (the
+oracle -- a C port of the reference algorithm, the Rust reference cannot be built here -- timed on a
+bounded sample of the same frames on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W4K, H4K = 3840, 2160
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=64, help="frames per rank per step")
+    ap.add_argument("--kind", default="S1", choices=["S1", "S2", "S3"])
+    ap.add_argument("--rgb", action="store_true", help="RGB8 frames (config 4/5) instead of gray8")
+    ap.add_argument("--width", type=int, default=W4K)
+    ap.add_argument("--height", type=int, default=H4K)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--check-frames", type=int, default=2, help="frames byte-compared with the oracle before timing")
+    return ap.parse_args()
+
+
+def cpu_baseline(frames_np, budget_s):
+    """Oracle (C port of the reference's serial algorithm) on host cores: 1 core, then all cores."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from tests import oracle_lib
+
+    oracle = oracle_lib.load()
+    px = frames_np[0].shape[0] * frames_np[0].shape[1]
+    # one core (the reference is single-threaded, src/compression.rs:117-146)
+    t0 = time.perf_counter()
+    done = 0
+    for f in frames_np:
+        oracle.compress(f)
+        done += 1
+        if time.perf_counter() - t0 > budget_s * 0.45:
+            break
+    t1 = time.perf_counter() - t0
+    single = {"value": done * px / t1 / 1e6, "unit": "MPix/s", "cores": 1, "kind": "port",
+              "sample": "%d of the batch's %dx%d frames, oracle/felics_oracle.c -O3, 1 thread" % (done, frames_np[0].shape[1], frames_np[0].shape[0])}
+    # all cores, one image per thread (ctypes releases the GIL inside the C call)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    per_frame = t1 / done
+    n = max(cores, min(len(frames_np) * 8, int(budget_s * 0.45 / per_frame) * cores))
+    n = max(cores, (n // cores) * cores)
+    work = [frames_np[i % len(frames_np)] for i in range(n)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(oracle.compress, work))
+    t2 = time.perf_counter() - t0
+    multi = {"value": n * px / t2 / 1e6, "unit": "MPix/s", "cores": cores, "kind": "port",
+             "sample": "%d frame encodes over %d threads, one image per thread" % (n, cores)}
+    return single, multi
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import felics_amd
+    from felics_amd import synth_torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # RCCL; barrier + MAX of the time only
+
+    W, H, F = args.width, args.height, args.frames
+    channels = 3 if args.rgb else 1
+    npix = W * H
+    # this rank's shard of the job: frames rank*F .. rank*F + F - 1, generated straight into HBM
+    frames = torch.empty((F, H, W, channels) if args.rgb else (F, H, W), dtype=torch.uint8, device=dev)
+    for i in range(F):
+        f = rank * F + i
+        frames[i] = synth_torch.rgb8(W, H, f, device=dev) if args.rgb else synth_torch.gray8(W, H, f, args.kind, device=dev)
+    d_out = torch.empty(int(F * npix * channels * 1.25) + (1 << 20), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    enc = felics_amd.Encoder(local)
+    color = 1 if args.rgb else 0
+
+    def step():
+        return enc.compress_batch_device(frames.data_ptr(), F, W, H, color, 0, d_out.data_ptr(), d_out.numel())
+
+    # ---- parity first: byte-compare a few streams with the oracle, checksum the rest ----
+    offs, lens = step()
+    host = d_out[: int(offs[-1] + lens[-1])].cpu().numpy()
+    from tests import oracle_lib
+
+    oracle = oracle_lib.load()
+    checked = 0
+    for i in range(min(args.check_frames, F)):
+        want = oracle.compress(frames[i].cpu().numpy())
+        got = host[int(offs[i]): int(offs[i] + lens[i])].tobytes()
+        if got != want:
+            raise SystemExit("rank %d frame %d: GPU stream differs from the oracle" % (rank, i))
+        checked += 1
+    ref_sum = int(host.astype(np.uint64).sum())
+    total_bytes = int(lens.sum())
+
+    for _ in range(args.warmup):
+        step()
+    enc.set_profiling(True)
+    stage_acc = {}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()  # synchronous: returns when the streams are complete in HBM
+        for k, v in enc.stage_ms().items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    enc.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # the timed steps must have produced the same bytes as the checked one
+    host2 = d_out[: int(offs[-1] + lens[-1])].cpu().numpy()
+    if int(host2.astype(np.uint64).sum()) != ref_sum:
+        raise SystemExit("rank %d: output changed between steps" % rank)
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        ms_per_step = elapsed / steps * 1e3
+        value = world * F * npix * steps / elapsed / 1e6  # MPix/s, whole job
+        stage_ms = {k: v / steps for k, v in stage_acc.items()}
+        dom = max(stage_ms, key=stage_ms.get) if stage_ms else None
+        alg_bytes = F * npix * channels  # 1 B/pixel/channel read, SURVEY.md §8(d)
+        roofline = None
+        if dom and stage_ms[dom] > 0:
+            achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(stage_ms[dom], 4)}
+        pipeline_gbs = alg_bytes / (ms_per_step * 1e-3) / 1e9
+        cpu1 = cpum = None
+        if args.cpu_seconds > 0:
+            sample = [frames[i].cpu().numpy() for i in range(min(F, 16))]
+            cpu1, cpum = cpu_baseline(sample, args.cpu_seconds)
+            cpu1["value"] = round(cpu1["value"], 2)
+            cpum["value"] = round(cpum["value"], 2)
+        line = {
+            "metric": "encode MPix/s on 4K 8-bit grayscale batch (bit-exact); % HBM-read roofline",
+            "value": round(value, 1), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "batch of %d synthetic %s %dx%d 8-bit %s frames per GPU, resident in HBM"
+                                   % (F, "S1-RGB" if args.rgb else args.kind, W, H, "RGB" if args.rgb else "grayscale"),
+                       "frames_per_gpu": F, "width": W, "height": H, "channels": channels,
+                       "sharding": "frames split across ranks, no collective"},
+            "roofline": roofline,
+            "cpu_baseline": cpu1,
+            "cpu_baseline_all_cores": cpum,
+            "pipeline": {"achieved_GBs": round(pipeline_gbs, 2), "frac_of_hbm_peak": round(pipeline_gbs / HBM_PEAK_GBS, 5),
+                         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}},
+            "parity": {"frames_byte_compared_with_oracle": checked, "output_checksum_stable": True,
+                       "compressed_bytes_per_step_rank0": total_bytes,
+                       "bits_per_pixel": round(total_bytes * 8 / (F * npix), 4)},
+        }
+        print(json.dumps(line), flush=True)
+    enc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,40 @@
+"""Builds the native parts in-tree: felics_amd/_build/libfelics.so (+ cfelics, dfelics).
+
+hipcc cross-compiles gfx950 code without a GPU, so this runs in the build container; the built
+files travel to the GPU box with the repository snapshot.
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libfelics.so")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def sources():
+    inc = os.path.join(os.path.dirname(HERE), "include", "felics.h")
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [inc]
+
+
+def build(force=False, quiet=True):
+    """make -C csrc all; returns the path of libfelics.so."""
+    targets = [LIB, os.path.join(OUT, "cfelics"), os.path.join(OUT, "dfelics")]
+    if force or any(_stale(t, sources()) for t in targets):
+        cmd = ["make", "-C", CSRC, "all"] + (["-B"] if force else [])
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL if quiet else None)
+    return LIB
+
+
+def ensure_lib():
+    """Path of libfelics.so, building it only if it is missing (the GPU box ships it prebuilt)."""
+    if not os.path.exists(LIB):
+        build()
+    return LIB

@@ -1,0 +1,456 @@
+// felics_api.cpp -- host side of libfelics: the C ABI of include/felics.h on top of the
+// gfx950 kernels.  One context = one GPU + one HIP stream + a grow-only workspace in HBM.
+//
+// Encode is GPU-only by design: there is no CPU encode path in this library.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/felics.h"
+#include "felics_kernels.h"
+
+using namespace felics;
+
+namespace {
+
+enum Stage { ST_PLANES = 0, ST_HIST, ST_OFFSETS, ST_SCATTER, ST_RESOLVE, ST_LENGTHS, ST_BITSCAN, ST_ZERO, ST_PACK, ST_COUNT };
+const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "resolve", "lengths", "bitscan", "zero", "pack"};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct felics_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool profiling = false;
+    hipEvent_t ev[ST_COUNT][2] = {};
+    bool ev_used[ST_COUNT] = {};
+    float stage_ms[ST_COUNT] = {};
+
+    // workspace (HBM), grown on demand and kept between calls
+    DevBuf in, planes, counts, chain_len, chain_base, scalars, sorted_e, k_sorted, slot_of, tile_bits, tile_bitoff,
+        image_bytes, image_off, out;
+    std::vector<uint64_t> h_sizes;  // image_bytes[n] followed by image_off[n+1]
+};
+
+namespace {
+
+int hip_fail(felics_ctx *ctx, hipError_t e, const char *what) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    if (ctx) ctx->err = buf;
+    return FELICS_E_HIP;
+}
+
+#define HIP_TRY(ctx, call)                                          \
+    do {                                                            \
+        hipError_t e__ = (call);                                    \
+        if (e__ != hipSuccess) return hip_fail(ctx, e__, #call);    \
+    } while (0)
+
+int reserve(felics_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return FELICS_OK;
+    if (b.p) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;  // a little slack so near-equal batches do not realloc
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return FELICS_OK;
+}
+
+void release(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+struct StageTimer {
+    felics_ctx *ctx;
+    int st;
+    StageTimer(felics_ctx *c, int s) : ctx(c), st(s) {
+        if (ctx->profiling) {
+            (void)hipEventRecord(ctx->ev[st][0], ctx->stream);
+            ctx->ev_used[st] = true;
+        }
+    }
+    ~StageTimer() {
+        if (ctx->profiling) (void)hipEventRecord(ctx->ev[st][1], ctx->stream);
+    }
+};
+
+int check_args(uint32_t w, uint32_t h, int color, int depth) {
+    if (color != FELICS_COLOR_GRAY && color != FELICS_COLOR_RGB) return FELICS_E_INVALID_COLOR_TYPE;
+    if (depth != FELICS_DEPTH_8 && depth != FELICS_DEPTH_16) return FELICS_E_INVALID_PIXEL_DEPTH;
+    // compress_channel unwraps width.checked_mul(height) (compression.rs:86): reported, not a panic
+    if ((uint64_t)w * h > 0xFFFFFFFFull) return FELICS_E_INVALID_DIMENSIONS;
+    return FELICS_OK;
+}
+
+void header_bytes(uint8_t *o, uint32_t w, uint32_t h, int color, int depth) {
+    memcpy(o, "FLCS", 4);
+    o[4] = (uint8_t)color;
+    o[5] = (uint8_t)depth;
+    for (int i = 0; i < 4; i++) {
+        o[6 + i] = (uint8_t)(w >> (24 - 8 * i));
+        o[10 + i] = (uint8_t)(h >> (24 - 8 * i));
+    }
+}
+
+// Stages up to the bit scan: after this the size of every stream is known on the host.
+template <typename T, typename ET>
+int analyse(felics_ctx *ctx, const Geometry &g, const T *d_planes) {
+    const size_t nsamples = (size_t)g.nplanes * g.npix;
+    int rc;
+    if ((rc = reserve(ctx, ctx->counts, (size_t)g.nplanes * g.sort_tiles * NCTX * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->chain_len, (size_t)g.nplanes * NCTX * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->chain_base, (size_t)g.nplanes * NCTX * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->scalars, 64)) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->sorted_e, nsamples * sizeof(ET))) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->k_sorted, nsamples)) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->slot_of, nsamples * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->tile_bits, (size_t)g.nplanes * g.pack_tiles * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->tile_bitoff, (size_t)g.nplanes * g.pack_tiles * 8)) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->image_bytes, (size_t)g.nimages * 8)) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->image_off, (size_t)(g.nimages + 1) * 8)) != 0) return rc;
+
+    hipStream_t s = ctx->stream;
+    auto *counts = (uint32_t *)ctx->counts.p;
+    auto *chain_len = (uint32_t *)ctx->chain_len.p;
+    auto *chain_base = (uint32_t *)ctx->chain_base.p;
+    {
+        StageTimer t(ctx, ST_HIST);
+        launch_hist<T>(s, d_planes, counts, g);
+    }
+    {
+        StageTimer t(ctx, ST_OFFSETS);
+        launch_offsets(s, counts, chain_len, chain_base, (uint32_t *)ctx->scalars.p, g);
+    }
+    {
+        StageTimer t(ctx, ST_SCATTER);
+        launch_scatter<T, ET>(s, d_planes, counts, chain_base, (ET *)ctx->sorted_e.p, (uint32_t *)ctx->slot_of.p, g);
+    }
+    {
+        StageTimer t(ctx, ST_RESOLVE);
+        launch_resolve<ET>(s, (const ET *)ctx->sorted_e.p, (uint8_t *)ctx->k_sorted.p, chain_base, chain_len, g);
+    }
+    {
+        StageTimer t(ctx, ST_LENGTHS);
+        launch_lengths<T>(s, d_planes, (const uint32_t *)ctx->slot_of.p, (const uint8_t *)ctx->k_sorted.p,
+                          (uint32_t *)ctx->tile_bits.p, g);
+    }
+    {
+        StageTimer t(ctx, ST_BITSCAN);
+        launch_bitscan(s, (const uint32_t *)ctx->tile_bits.p, (uint64_t *)ctx->tile_bitoff.p,
+                       (uint64_t *)ctx->image_bytes.p, (uint64_t *)ctx->image_off.p, g);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->h_sizes.resize((size_t)g.nimages * 2 + 1);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_sizes.data(), ctx->image_bytes.p, (size_t)g.nimages * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_sizes.data() + g.nimages, ctx->image_off.p, (size_t)(g.nimages + 1) * 8,
+                                hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return FELICS_OK;
+}
+
+template <typename T>
+int emit(felics_ctx *ctx, const Geometry &g, const T *d_planes, uint8_t *d_out) {
+    hipStream_t s = ctx->stream;
+    {
+        StageTimer t(ctx, ST_ZERO);
+        launch_zero_streams(s, (uint32_t *)d_out, (const uint64_t *)ctx->image_off.p, g);
+    }
+    {
+        StageTimer t(ctx, ST_PACK);
+        launch_pack<T>(s, d_planes, (const uint32_t *)ctx->slot_of.p, (const uint8_t *)ctx->k_sorted.p,
+                       (const uint64_t *)ctx->tile_bitoff.p, (const uint32_t *)ctx->tile_bits.p,
+                       (const uint64_t *)ctx->image_off.p, d_out, g);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return FELICS_OK;
+}
+
+void collect_timing(felics_ctx *ctx) {
+    if (!ctx->profiling) return;
+    for (int i = 0; i < ST_COUNT; i++) {
+        ctx->stage_ms[i] = 0.f;
+        if (ctx->ev_used[i]) (void)hipEventElapsedTime(&ctx->stage_ms[i], ctx->ev[i][0], ctx->ev[i][1]);
+    }
+}
+
+// images per sub-batch so that slots / chain bases stay below 2^32
+size_t max_images_per_pass(uint64_t npix, uint32_t planes) {
+    const uint64_t per_image = npix * planes;
+    if (per_image == 0) return SIZE_MAX;
+    return (size_t)std::max<uint64_t>(1, 0xF0000000ull / per_image);
+}
+
+// Encode `n` same-shape frames resident in device memory into d_out (device).
+// If d_out is NULL the context's own output buffer is used (and grown).
+int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, uint32_t h, int color, int depth,
+                  uint8_t *d_out, size_t d_out_cap, uint64_t *offsets, uint64_t *lens, uint8_t **used_out) {
+    const uint32_t planes = color == FELICS_COLOR_RGB ? 3 : 1;
+    const uint64_t npix = (uint64_t)w * h;
+    if (depth == FELICS_DEPTH_16) return FELICS_E_UNSUPPORTED;  // GPU path: 8-bit samples
+    if (npix * planes >= 0xF0000000ull) return FELICS_E_UNSUPPORTED;
+    for (int i = 0; i < ST_COUNT; i++) ctx->ev_used[i] = false;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    if (npix == 0) {
+        // (0,_) | (_,0): header + two zero i32 per plane (compression.rs:94-98); nothing to compute
+        const size_t sz = 14 + 8 * planes;
+        const size_t stride = (sz + 15) & ~(size_t)15;
+        const size_t need = stride * n;
+        if (!d_out) {
+            int rc = reserve(ctx, ctx->out, need);
+            if (rc) return rc;
+            d_out = (uint8_t *)ctx->out.p;
+            d_out_cap = ctx->out.cap;
+        }
+        if (need > d_out_cap) {
+            if (n) lens[0] = need;
+            return FELICS_E_BUFFER_TOO_SMALL;
+        }
+        std::vector<uint8_t> tmp(need, 0);
+        for (size_t i = 0; i < n; i++) {
+            header_bytes(tmp.data() + i * stride, w, h, color, depth);
+            offsets[i] = i * stride;
+            lens[i] = sz;
+        }
+        if (need) HIP_TRY(ctx, hipMemcpy(d_out, tmp.data(), need, hipMemcpyHostToDevice));
+        if (used_out) *used_out = d_out;
+        return FELICS_OK;
+    }
+
+    // Sub-batches keep every index below 2^32; streams of later sub-batches follow the earlier ones.
+    const size_t per_pass = max_images_per_pass(npix, planes);
+    const size_t frame_bytes = (size_t)npix * planes;  // u8 samples
+    uint64_t out_base = 0;
+    const bool own_out = d_out == nullptr;
+    if (own_out && n > per_pass) return FELICS_E_UNSUPPORTED;  // host API splits before calling
+    for (size_t first = 0; first < n; first += per_pass) {
+        const size_t cnt = std::min(per_pass, n - first);
+        Geometry g;
+        g.W = w;
+        g.H = h;
+        g.npix = (uint32_t)npix;
+        g.nimages = (uint32_t)cnt;
+        g.planes_per_image = planes;
+        g.nplanes = (uint32_t)(cnt * planes);
+        g.sort_tiles = (uint32_t)((npix + SORT_TILE - 1) / SORT_TILE);
+        g.pack_tiles = (uint32_t)((npix + PACK_TILE - 1) / PACK_TILE);
+        g.color = (uint32_t)color;
+        g.depth = (uint32_t)depth;
+        const uint8_t *src = (const uint8_t *)d_pixels + first * frame_bytes;
+        int rc;
+        const void *d_planes = src;
+        if (planes == 3) {
+            if ((rc = reserve(ctx, ctx->planes, (size_t)g.nplanes * npix * 2)) != 0) return rc;
+            StageTimer t(ctx, ST_PLANES);
+            launch_rgb8_to_planes(ctx->stream, src, (int16_t *)ctx->planes.p, g.npix, g.nimages);
+            d_planes = ctx->planes.p;
+        }
+        rc = planes == 3 ? analyse<int16_t, uint16_t>(ctx, g, (const int16_t *)d_planes)
+                         : analyse<uint8_t, uint8_t>(ctx, g, (const uint8_t *)d_planes);
+        if (rc) return rc;
+        const uint64_t need = ctx->h_sizes[(size_t)cnt * 2];  // image_off[cnt]
+        if (own_out) {
+            if ((rc = reserve(ctx, ctx->out, need)) != 0) return rc;
+            d_out = (uint8_t *)ctx->out.p;
+            d_out_cap = ctx->out.cap;
+        }
+        if (out_base + need > d_out_cap) {
+            lens[0] = out_base + need;  // lower bound when more sub-batches follow
+            return FELICS_E_BUFFER_TOO_SMALL;
+        }
+        rc = planes == 3 ? emit<int16_t>(ctx, g, (const int16_t *)d_planes, d_out + out_base)
+                         : emit<uint8_t>(ctx, g, (const uint8_t *)d_planes, d_out + out_base);
+        if (rc) return rc;
+        for (size_t i = 0; i < cnt; i++) {
+            lens[first + i] = ctx->h_sizes[i];
+            offsets[first + i] = out_base + ctx->h_sizes[cnt + i];
+        }
+        out_base += need;
+    }
+    collect_timing(ctx);
+    if (used_out) *used_out = d_out;
+    return FELICS_OK;
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------------
+// C ABI
+// --------------------------------------------------------------------------------------------
+
+extern "C" {
+
+int felics_ctx_create(int device, felics_ctx **out) {
+    if (!out) return FELICS_E_INVALID_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0 || device < 0 || device >= count) return FELICS_E_HIP;
+    felics_ctx *ctx = new (std::nothrow) felics_ctx();
+    if (!ctx) return FELICS_E_IO;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return FELICS_E_HIP;
+    }
+    for (int i = 0; i < ST_COUNT; i++)
+        for (int j = 0; j < 2; j++)
+            if (hipEventCreate(&ctx->ev[i][j]) != hipSuccess) {
+                felics_ctx_destroy(ctx);
+                return FELICS_E_HIP;
+            }
+    *out = ctx;
+    return FELICS_OK;
+}
+
+void felics_ctx_destroy(felics_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->in, &ctx->planes, &ctx->counts, &ctx->chain_len, &ctx->chain_base, &ctx->scalars,
+                      &ctx->sorted_e, &ctx->k_sorted, &ctx->slot_of, &ctx->tile_bits, &ctx->tile_bitoff,
+                      &ctx->image_bytes, &ctx->image_off, &ctx->out};
+    for (DevBuf *b : bufs) release(*b);
+    for (int i = 0; i < ST_COUNT; i++)
+        for (int j = 0; j < 2; j++)
+            if (ctx->ev[i][j]) (void)hipEventDestroy(ctx->ev[i][j]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+size_t felics_max_compressed_size(uint32_t w, uint32_t h, int color, int depth) {
+    const uint64_t planes = color == FELICS_COLOR_RGB ? 3 : 1;
+    const uint64_t emax = depth == FELICS_DEPTH_8 ? (color ? 509u : 254u) : (color ? 131069u : 65534u);
+    const uint64_t px = (uint64_t)w * h;
+    const uint64_t bits = planes * 64u + planes * px * (3u + emax);
+    return (size_t)(14u + (bits + 7u) / 8u);
+}
+
+int felics_compress_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, uint32_t h, int color,
+                                 int depth, void *d_out, size_t d_out_cap, uint64_t *offsets, uint64_t *lens) {
+    if (!ctx || !offsets || !lens || !d_out || (!d_pixels && n && (uint64_t)w * h)) return FELICS_E_INVALID_ARGUMENT;
+    int rc = check_args(w, h, color, depth);
+    if (rc) return rc;
+    if (n == 0) return FELICS_OK;
+    return encode_device(ctx, n, d_pixels, w, h, color, depth, (uint8_t *)d_out, d_out_cap, offsets, lens, nullptr);
+}
+
+int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, uint32_t w, uint32_t h, int color,
+                          int depth, uint8_t *const *outs, const size_t *caps, size_t *lens) {
+    if (!ctx || (n && (!pixels || !outs || !caps || !lens))) return FELICS_E_INVALID_ARGUMENT;
+    int rc = check_args(w, h, color, depth);
+    if (rc) return rc;
+    if (n == 0) return FELICS_OK;
+    if (depth == FELICS_DEPTH_16) return FELICS_E_UNSUPPORTED;
+    const uint32_t planes = color == FELICS_COLOR_RGB ? 3 : 1;
+    const size_t frame_bytes = (size_t)w * h * planes;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t per_pass = max_images_per_pass((uint64_t)w * h, planes);
+    std::vector<uint64_t> offs, sizes;
+    int result = FELICS_OK;
+    for (size_t first = 0; first < n; first += per_pass) {
+        const size_t cnt = std::min(per_pass, n - first);
+        if ((rc = reserve(ctx, ctx->in, frame_bytes * cnt)) != 0) return rc;
+        for (size_t i = 0; i < cnt && frame_bytes; i++) {
+            if (!pixels[first + i]) return FELICS_E_INVALID_ARGUMENT;
+            HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)ctx->in.p + i * frame_bytes, pixels[first + i], frame_bytes,
+                                        hipMemcpyHostToDevice, ctx->stream));
+        }
+        offs.assign(cnt, 0);
+        sizes.assign(cnt, 0);
+        uint8_t *d_out = nullptr;
+        rc = encode_device(ctx, cnt, ctx->in.p, w, h, color, depth, nullptr, 0, offs.data(), sizes.data(), &d_out);
+        if (rc) return rc;
+        for (size_t i = 0; i < cnt; i++) {
+            lens[first + i] = (size_t)sizes[i];
+            if (sizes[i] > caps[first + i] || !outs[first + i]) {
+                result = FELICS_E_BUFFER_TOO_SMALL;  // lens[] still reports every size needed
+                continue;
+            }
+            HIP_TRY(ctx, hipMemcpyAsync(outs[first + i], d_out + offs[i], (size_t)sizes[i], hipMemcpyDeviceToHost,
+                                        ctx->stream));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return result;
+}
+
+int felics_compress(felics_ctx *ctx, const void *pixels, uint32_t w, uint32_t h, int color, int depth, uint8_t *out,
+                    size_t cap, size_t *out_len) {
+    if (!out_len) return FELICS_E_INVALID_ARGUMENT;
+    const void *px[1] = {pixels};
+    uint8_t *outs[1] = {out};
+    size_t caps[1] = {cap};
+    size_t lens[1] = {0};
+    if (!pixels && (uint64_t)w * h != 0) return FELICS_E_INVALID_ARGUMENT;
+    static const uint8_t dummy = 0;
+    if (!pixels) px[0] = &dummy;
+    int rc = felics_compress_batch(ctx, 1, px, w, h, color, depth, outs, caps, lens);
+    *out_len = lens[0];
+    return rc;
+}
+
+int felics_write_header(const felics_header *hdr, uint8_t *out, size_t cap) {
+    if (!hdr || !out) return FELICS_E_INVALID_ARGUMENT;
+    if (cap < FELICS_HEADER_BYTES) return FELICS_E_BUFFER_TOO_SMALL;
+    if (hdr->color_type > 1) return FELICS_E_INVALID_COLOR_TYPE;
+    if (hdr->pixel_depth > 1) return FELICS_E_INVALID_PIXEL_DEPTH;
+    header_bytes(out, hdr->width, hdr->height, hdr->color_type, hdr->pixel_depth);
+    return FELICS_OK;
+}
+
+const char *felics_strerror(int code) {
+    switch (code) {
+        case FELICS_OK: return "ok";
+        case FELICS_E_IO: return "I/O error (truncated stream or allocation failure)";
+        case FELICS_E_INVALID_VALUE: return "a decoded value does not fit the image bit depth";
+        case FELICS_E_VALUE_OVERFLOW: return "arithmetic overflow while decoding";
+        case FELICS_E_INVALID_DIMENSIONS: return "invalid channel dimensions";
+        case FELICS_E_INVALID_COLOR_TYPE: return "invalid color type";
+        case FELICS_E_INVALID_PIXEL_DEPTH: return "invalid pixel depth";
+        case FELICS_E_INVALID_SIGNATURE: return "not a felics file (bad signature)";
+        case FELICS_E_BUFFER_TOO_SMALL: return "output buffer too small";
+        case FELICS_E_HIP: return "no usable HIP device or HIP runtime error";
+        case FELICS_E_UNSUPPORTED: return "not supported by the GPU encoder in this build";
+        case FELICS_E_INVALID_ARGUMENT: return "invalid argument";
+        default: return "unknown error";
+    }
+}
+
+const char *felics_last_error(const felics_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int felics_set_profiling(felics_ctx *ctx, int enabled) {
+    if (!ctx) return FELICS_E_INVALID_ARGUMENT;
+    ctx->profiling = enabled != 0;
+    return FELICS_OK;
+}
+
+int felics_stage_count(void) { return ST_COUNT; }
+
+const char *felics_stage_name(int stage) { return stage >= 0 && stage < ST_COUNT ? kStageNames[stage] : ""; }
+
+int felics_get_stage_ms(const felics_ctx *ctx, float *ms, int cap) {
+    if (!ctx || !ms) return FELICS_E_INVALID_ARGUMENT;
+    int n = cap < ST_COUNT ? cap : (int)ST_COUNT;
+    for (int i = 0; i < n; i++) ms[i] = ctx->stage_ms[i];
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// felics_kernels.h -- launch interface between the host pipeline (felics_api.cpp)
+// and the gfx950 kernels (felics_kernels.hip).  Not part of the public C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+namespace felics {
+
+// u8 samples (and Y/Co/Cg of RGB8): contexts 0..510 (traits.rs:28), table padded to 512.
+constexpr uint32_t NCTX = 512;
+// pixels one wave partitions by context in the hist / scatter stages
+constexpr uint32_t SORT_TILE = 16384;
+// pack stage: 256 threads x 16 consecutive pixels
+constexpr uint32_t PACK_THREADS = 256;
+constexpr uint32_t PACK_PER_THREAD = 16;
+constexpr uint32_t PACK_TILE = PACK_THREADS * PACK_PER_THREAD;
+// LDS bit window of the pack stage: 4096 words = 16 KiB = 32 bits per pixel of a tile
+constexpr uint32_t PACK_WIN_WORDS = 4096;
+
+struct Geometry {
+    uint32_t W, H;
+    uint32_t npix;              // W*H, pixels per plane
+    uint32_t nimages;
+    uint32_t planes_per_image;  // 1 gray, 3 rgb
+    uint32_t nplanes;           // nimages * planes_per_image
+    uint32_t sort_tiles;        // ceil(npix / SORT_TILE)
+    uint32_t pack_tiles;        // ceil(npix / PACK_TILE)
+    uint32_t color, depth;      // header fields
+};
+
+void launch_rgb8_to_planes(hipStream_t s, const uint8_t *rgb, int16_t *planes, uint32_t npix, uint32_t nimg);
+
+template <typename T>
+void launch_hist(hipStream_t s, const T *planes, uint32_t *counts, const Geometry &g);
+
+void launch_offsets(hipStream_t s, uint32_t *counts, uint32_t *chain_len, uint32_t *chain_base,
+                    uint32_t *total_events, const Geometry &g);
+
+template <typename T, typename ET>
+void launch_scatter(hipStream_t s, const T *planes, const uint32_t *tile_off, const uint32_t *chain_base,
+                    ET *sorted_e, uint32_t *slot_of, const Geometry &g);
+
+template <typename ET>
+void launch_resolve(hipStream_t s, const ET *sorted_e, uint8_t *k_sorted, const uint32_t *chain_base,
+                    const uint32_t *chain_len, const Geometry &g);
+
+template <typename T>
+void launch_lengths(hipStream_t s, const T *planes, const uint32_t *slot_of, const uint8_t *k_sorted,
+                    uint32_t *tile_bits, const Geometry &g);
+
+void launch_bitscan(hipStream_t s, const uint32_t *tile_bits, uint64_t *tile_bitoff, uint64_t *image_bytes,
+                    uint64_t *image_off, const Geometry &g);
+
+void launch_zero_streams(hipStream_t s, uint32_t *out, const uint64_t *image_off, const Geometry &g);
+
+template <typename T>
+void launch_pack(hipStream_t s, const T *planes, const uint32_t *slot_of, const uint8_t *k_sorted,
+                 const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint64_t *image_off, uint8_t *out,
+                 const Geometry &g);
+
+}  // namespace felics

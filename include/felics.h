@@ -1,0 +1,132 @@
+/*
+ * felics.h -- C ABI of libfelics: MI355X-native FELICS lossless image codec.
+ *
+ * Drop-in boundary for the encode hot path of visanalexandru/felics.  The
+ * reference has no FFI layer of its own: its boundary is the public Rust
+ * surface in src/compression.rs / src/compression/traits.rs and the
+ * cfelics/dfelics command lines.  Every entry point below names the reference
+ * interface it replaces (paths relative to the reference repository); the Rust
+ * `extern "C"` block a maintainer would add is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; no exceptions or aborts cross this boundary;
+ *   - pixels are row-major, native-endian u8 (depth 0) or u16 (depth 1),
+ *     interleaved RGBRGB... when color == FELICS_COLOR_RGB -- the layout of
+ *     `ImageBuffer::as_raw()` (compression.rs:276, :338);
+ *   - the caller owns every buffer; the library keeps no pointer after return;
+ *   - a context is bound to one GPU and one HIP stream and is not thread-safe:
+ *     use one context per host thread / per GPU (the reference is single
+ *     threaded and re-entrant on distinct images);
+ *   - ENCODE RUNS ON THE GPU ONLY.  There is no CPU encode fallback: without a
+ *     usable HIP device felics_ctx_create() returns FELICS_E_HIP.
+ *   - every function returning int returns FELICS_OK (0) or a negative code.
+ */
+#ifndef FELICS_H
+#define FELICS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error.rs:4-19 DecompressionError variants, then the codes this ABI adds */
+#define FELICS_OK 0
+#define FELICS_E_IO (-1)                  /* DecompressionError::IoError (truncated stream) */
+#define FELICS_E_INVALID_VALUE (-2)       /* ::InvalidValue   */
+#define FELICS_E_VALUE_OVERFLOW (-3)      /* ::ValueOverflow  */
+#define FELICS_E_INVALID_DIMENSIONS (-4)  /* ::InvalidDimensions */
+#define FELICS_E_INVALID_COLOR_TYPE (-5)  /* ::InvalidColorType  */
+#define FELICS_E_INVALID_PIXEL_DEPTH (-6) /* ::InvalidPixelDepth */
+#define FELICS_E_INVALID_SIGNATURE (-7)   /* ::InvalidSignature  */
+#define FELICS_E_BUFFER_TOO_SMALL (-8)    /* caller's output buffer cannot hold the result */
+#define FELICS_E_HIP (-9)                 /* no device / HIP runtime error (see felics_last_error) */
+#define FELICS_E_UNSUPPORTED (-10)        /* valid request this build cannot run on the GPU */
+#define FELICS_E_INVALID_ARGUMENT (-11)   /* NULL pointer, bad enum value */
+
+/* format.rs:8-12 ColorType, format.rs:27-31 PixelDepth (wire values) */
+#define FELICS_COLOR_GRAY 0
+#define FELICS_COLOR_RGB 1
+#define FELICS_DEPTH_8 0
+#define FELICS_DEPTH_16 1
+
+/* format.rs:44-49 `pub struct Header` */
+typedef struct felics_header {
+    uint8_t color_type;
+    uint8_t pixel_depth;
+    uint32_t width;
+    uint32_t height;
+} felics_header;
+
+#define FELICS_HEADER_BYTES 14 /* "FLCS", u8 colour, u8 depth, u32 BE width, u32 BE height */
+
+typedef struct felics_ctx felics_ctx;
+
+/* Binds a context to HIP device `device` (>= 0).  Replaces nothing in the
+ * reference (it has no device); it is the handle the Rust wrapper would keep
+ * in a `struct Encoder`. */
+int felics_ctx_create(int device, felics_ctx **out);
+void felics_ctx_destroy(felics_ctx *ctx);
+
+/* Upper bound of the .felics size of a w x h image (worst case of the code:
+ * 2 flag bits + unary(emax) + terminator at k = 0 for every pixel). */
+size_t felics_max_compressed_size(uint32_t w, uint32_t h, int color, int depth);
+
+/* Replaces `<ImageBuffer<Luma<T>|Rgb<T>, Vec<T>> as CompressDecompress>::compress`
+ * (compression.rs:255-282, :322-371) and `compress_image` (:412-418): writes the
+ * WHOLE file (14-byte header + bit stream, zero padded to a byte) to `out`.
+ * A Rust `compress<W: Write>(&self, to: W)` is: call this into a Vec<u8>, then
+ * `to.write_all(&buf[..out_len])`.  On FELICS_E_BUFFER_TOO_SMALL *out_len holds
+ * the size needed. */
+int felics_compress(felics_ctx *ctx, const void *pixels, uint32_t w, uint32_t h, int color,
+                    int depth, uint8_t *out, size_t cap, size_t *out_len);
+
+/* n images of one shape in one submission (BASELINE config 3/5: a batch of
+ * frames on one GPU).  pixels[i], outs[i], caps[i], lens[i] per image.  Images
+ * are independent streams, exactly n calls of felics_compress. */
+int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, uint32_t w,
+                          uint32_t h, int color, int depth, uint8_t *const *outs,
+                          const size_t *caps, size_t *lens);
+
+/* Same, with input frames and output already in DEVICE memory (what a capture
+ * or decode pipeline that lives on the GPU calls; what bench.py times).
+ *   d_pixels : n frames back to back (w*h*channels samples each)
+ *   d_out    : device buffer of d_out_cap bytes; stream i is written at
+ *              offsets[i] (16-byte aligned, ascending) with lens[i] bytes
+ *   offsets, lens : HOST arrays of n entries, filled on return
+ * On FELICS_E_BUFFER_TOO_SMALL lens[0] holds the capacity needed. */
+int felics_compress_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w,
+                                 uint32_t h, int color, int depth, void *d_out,
+                                 size_t d_out_cap, uint64_t *offsets, uint64_t *lens);
+
+/* Replaces `read_header` (format.rs:63-84). */
+int felics_read_header(const uint8_t *in, size_t len, felics_header *hdr);
+/* Replaces `write_header` (format.rs:51-61): writes FELICS_HEADER_BYTES bytes. */
+int felics_write_header(const felics_header *hdr, uint8_t *out, size_t cap);
+
+/* Replaces `decompress_image` / `CompressDecompress::decompress`
+ * (compression.rs:420-441, traits.rs:57-64).  Host (CPU) implementation: the
+ * entropy decoder is bit-serial per plane.  `pixels` receives
+ * width*height*channels samples of the depth the header states. */
+int felics_decompress(const uint8_t *in, size_t len, void *pixels, size_t pixels_cap,
+                      felics_header *hdr);
+
+/* Text for a code above; for FELICS_E_HIP felics_last_error(ctx) has the HIP message. */
+const char *felics_strerror(int code);
+const char *felics_last_error(const felics_ctx *ctx);
+
+/* ---- measurement hooks (bench.py) ----
+ * With profiling on, every kernel of the next submission is bracketed by HIP
+ * events on the context's stream; felics_get_stage_ms copies the last
+ * submission's per-stage milliseconds (names via felics_stage_name). */
+#define FELICS_MAX_STAGES 16
+int felics_set_profiling(felics_ctx *ctx, int enabled);
+int felics_stage_count(void);
+const char *felics_stage_name(int stage);
+int felics_get_stage_ms(const felics_ctx *ctx, float *ms, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FELICS_H */

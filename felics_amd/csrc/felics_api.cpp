@@ -36,8 +36,8 @@ struct felics_ctx {
     float stage_ms[ST_COUNT] = {};
 
     // workspace (HBM), grown on demand and kept between calls
-    DevBuf in, planes, counts, chain_len, chain_base, scalars, sorted_e, k_sorted, slot_of, tile_bits, tile_bitoff,
-        image_bytes, image_off, out;
+    DevBuf in, planes, counts, chain_len, chain_base, scalars, sorted_e, k_sorted, block_state, slot_of, tile_bits,
+        tile_bitoff, image_bytes, image_off, out;
     std::vector<uint64_t> h_sizes;  // image_bytes[n] followed by image_off[n+1]
 };
 
@@ -117,8 +117,10 @@ int analyse(felics_ctx *ctx, const Geometry &g, const T *d_planes) {
     if ((rc = reserve(ctx, ctx->chain_len, (size_t)g.nplanes * NCTX * 4)) != 0) return rc;
     if ((rc = reserve(ctx, ctx->chain_base, (size_t)g.nplanes * NCTX * 4)) != 0) return rc;
     if ((rc = reserve(ctx, ctx->scalars, 64)) != 0) return rc;
-    if ((rc = reserve(ctx, ctx->sorted_e, nsamples * sizeof(ET))) != 0) return rc;
-    if ((rc = reserve(ctx, ctx->k_sorted, nsamples)) != 0) return rc;
+    const size_t slots = (size_t)max_event_slots(g);
+    if ((rc = reserve(ctx, ctx->sorted_e, slots * sizeof(ET) + SORTED_PAD)) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->k_sorted, slots)) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->block_state, (size_t)max_event_blocks(g) * 32)) != 0) return rc;
     if ((rc = reserve(ctx, ctx->slot_of, nsamples * 4)) != 0) return rc;
     if ((rc = reserve(ctx, ctx->tile_bits, (size_t)g.nplanes * g.pack_tiles * 4)) != 0) return rc;
     if ((rc = reserve(ctx, ctx->tile_bitoff, (size_t)g.nplanes * g.pack_tiles * 8)) != 0) return rc;
@@ -143,7 +145,8 @@ int analyse(felics_ctx *ctx, const Geometry &g, const T *d_planes) {
     }
     {
         StageTimer t(ctx, ST_RESOLVE);
-        launch_resolve<ET>(s, (const ET *)ctx->sorted_e.p, (uint8_t *)ctx->k_sorted.p, chain_base, chain_len, g);
+        launch_resolve<ET>(s, (ET *)ctx->sorted_e.p, (uint8_t *)ctx->k_sorted.p, (uint32_t *)ctx->block_state.p,
+                           chain_base, chain_len, (const uint32_t *)ctx->scalars.p, g);
     }
     {
         StageTimer t(ctx, ST_LENGTHS);
@@ -194,7 +197,7 @@ void collect_timing(felics_ctx *ctx) {
 size_t max_images_per_pass(uint64_t npix, uint32_t planes) {
     const uint64_t per_image = npix * planes;
     if (per_image == 0) return SIZE_MAX;
-    return (size_t)std::max<uint64_t>(1, 0xF0000000ull / per_image);
+    return (size_t)std::max<uint64_t>(1, 0xE0000000ull / (per_image + 64ull * planes * NCTX));
 }
 
 // Encode `n` same-shape frames resident in device memory into d_out (device).
@@ -204,7 +207,7 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
     const uint32_t planes = color == FELICS_COLOR_RGB ? 3 : 1;
     const uint64_t npix = (uint64_t)w * h;
     if (depth == FELICS_DEPTH_16) return FELICS_E_UNSUPPORTED;  // GPU path: 8-bit samples
-    if (npix * planes >= 0xF0000000ull) return FELICS_E_UNSUPPORTED;
+    if (npix * planes >= 0xE0000000ull) return FELICS_E_UNSUPPORTED;
     for (int i = 0; i < ST_COUNT; i++) ctx->ev_used[i] = false;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
@@ -325,7 +328,7 @@ void felics_ctx_destroy(felics_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->in, &ctx->planes, &ctx->counts, &ctx->chain_len, &ctx->chain_base, &ctx->scalars,
-                      &ctx->sorted_e, &ctx->k_sorted, &ctx->slot_of, &ctx->tile_bits, &ctx->tile_bitoff,
+                      &ctx->sorted_e, &ctx->k_sorted, &ctx->block_state, &ctx->slot_of, &ctx->tile_bits, &ctx->tile_bitoff,
                       &ctx->image_bytes, &ctx->image_off, &ctx->out};
     for (DevBuf *b : bufs) release(*b);
     for (int i = 0; i < ST_COUNT; i++)

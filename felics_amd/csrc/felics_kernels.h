@@ -43,9 +43,19 @@ template <typename T, typename ET>
 void launch_scatter(hipStream_t s, const T *planes, const uint32_t *tile_off, const uint32_t *chain_base,
                     ET *sorted_e, uint32_t *slot_of, const Geometry &g);
 
+// Chains are padded to whole 64-event blocks: upper bounds of the slot / block counts of a pass.
+inline uint64_t max_event_slots(const Geometry &g) {
+    return (uint64_t)g.nplanes * g.npix + 64ull * g.nplanes * NCTX;
+}
+inline uint32_t max_event_blocks(const Geometry &g) { return (uint32_t)(max_event_slots(g) / 64); }
+
+// sorted_e needs max_event_slots() elements plus SORTED_PAD bytes (the spine reads 64 blocks ahead)
+constexpr size_t SORTED_PAD = 64 * 64 * 2 + 256;
+
 template <typename ET>
-void launch_resolve(hipStream_t s, const ET *sorted_e, uint8_t *k_sorted, const uint32_t *chain_base,
-                    const uint32_t *chain_len, const Geometry &g);
+void launch_resolve(hipStream_t s, ET *sorted_e, uint8_t *k_sorted, uint32_t *block_state,
+                    const uint32_t *chain_base, const uint32_t *chain_len, const uint32_t *total_slots,
+                    const Geometry &g);
 
 template <typename T>
 void launch_lengths(hipStream_t s, const T *planes, const uint32_t *slot_of, const uint8_t *k_sorted,

@@ -9,7 +9,7 @@
 //   offsets  scan the counts: every context's events form one CHAIN, stored contiguously
 //   scatter  stable partition of the events by context, raster order kept
 //   resolve  replay the Rice-parameter estimator along every chain
-//            (parameter_selection.rs:49-85): the only sequential dependency
+//            (parameter_selection.rs:49-85): spine (sequential, per chain) + assign (parallel)
 //   lengths  code length of every pixel -> bits per tile
 //   bitscan  exclusive scan of tile bits -> bit offset of every tile in its stream
 //   pack     build the codes (rice_coding.rs:26-38, phase_in_coding.rs:59-84,
@@ -190,10 +190,11 @@ __global__ void k_tile_offsets(uint32_t *__restrict__ counts, uint32_t *__restri
     chain_len[g] = run;
 }
 
-// Exclusive scan of chain_len over all (plane, ctx) -> chain_base; single block.
+// Exclusive scan of the chain lengths, each rounded up to a whole 64-event block, over all
+// (plane, ctx) -> chain_base; single block.  total_slots = end of the last chain.
 __global__ __launch_bounds__(1024) void k_chain_bases(const uint32_t *__restrict__ chain_len,
                                                       uint32_t *__restrict__ chain_base, uint32_t n,
-                                                      uint32_t *__restrict__ total_events) {
+                                                      uint32_t *__restrict__ total_slots) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(1024) void k_chain_bases(const uint32_t *__restrict
     __syncthreads();
     for (uint32_t base = 0; base < n; base += 1024) {
         uint32_t i = base + threadIdx.x;
-        uint32_t v = i < n ? chain_len[i] : 0;
+        uint32_t v = i < n ? ((chain_len[i] + 63u) & ~63u) : 0;
         uint32_t inc = wave_incl_scan(v);
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();
@@ -213,7 +214,18 @@ __global__ __launch_bounds__(1024) void k_chain_bases(const uint32_t *__restrict
         if (threadIdx.x == 1023) carry = c + woff + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total_events = carry;
+    if (threadIdx.x == 0) *total_slots = carry;
+}
+
+// Zero the padding events at the end of every chain's last block (value 0 adds nothing to a
+// block's sum of e >> k, and nothing after a chain's last real event is ever used).
+template <typename ET>
+__global__ void k_zero_padding(ET *__restrict__ sorted_e, const uint32_t *__restrict__ chain_base,
+                               const uint32_t *__restrict__ chain_len, uint32_t nchains) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchains) return;
+    const uint32_t n = chain_len[c], base = chain_base[c];
+    for (uint32_t i = n; i < ((n + 63u) & ~63u); i++) sorted_e[base + i] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -280,76 +292,200 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
 }
 
 // ------------------------------------------------------------------------------------------
-// resolve: replay KEstimator (parameter_selection.rs:49-85) along one chain per wave.
+// resolve: replay KEstimator (parameter_selection.rs:49-85) along every chain.
 //
-// State S[k] = accumulated Rice lengths for k = 0..5 (traits.rs:26).  For 64 consecutive events
-// the wave prefix-sums the six length vectors; while no halving happens the state seen by lane t
-// is S + P_excl(t).  `min(S + P_incl(t)) > 1024` (parameter_selection.rs:58-63) is monotone in t
-// because lengths are positive, so the first lane f where it holds is the next halving:
-// lanes <= f are final, S <- (S + P_incl(f)) >> 1, and later lanes continue from there.
+// State S[k] = accumulated Rice lengths for k = 0..5 (traits.rs:26).  While no halving happens the
+// state seen by event t is S + P_excl(t), P = prefix sums of the six length vectors.
+// `min(S + P_incl(t)) > 1024` (parameter_selection.rs:58-63) is monotone in t because lengths are
+// positive, so inside a run of events the first t where it holds is the next halving:
+// S <- (S + P_incl(t)) >> 1, and the following events continue from there.
 // get_k ties go to the LARGEST k (`<=` at parameter_selection.rs:79).
+//
+// Two kernels.  k_spine walks one chain per wave and only finds the state at the start of every
+// 64-event block: the one sequential dependency of the codec, so it is written for latency --
+// 64 blocks are fetched at a time, each lane sums one block, and a block whose end state still has
+// a counter <= 1024 is stepped over with one vector add; only a block that contains a halving is searched.
+// k_assign then gives every event its k, one wave per block, all blocks in parallel.
 // ------------------------------------------------------------------------------------------
 
+// sum of the packed elements of w, each shifted right by K (K = 0..5)
+template <int K>
+__device__ __forceinline__ uint32_t packed_shift_sum(uint32_t w, uint8_t) {  // 4 x u8
+    if (K == 0) return __builtin_amdgcn_sad_u8(w, 0u, 0u);
+    return __builtin_amdgcn_sad_u8((w >> K) & (0x01010101u * (0xFFu >> K)), 0u, 0u);
+}
+template <int K>
+__device__ __forceinline__ uint32_t packed_shift_sum(uint32_t w, uint16_t) {  // 2 x u16
+    const uint32_t x = (w >> K) & (0x00010001u * (0xFFFFu >> K));
+    return (x & 0xFFFFu) + (x >> 16);
+}
+
 template <typename ET>
-__global__ __launch_bounds__(256) void k_resolve(const ET *__restrict__ sorted_e, uint8_t *__restrict__ k_sorted,
-                                                 const uint32_t *__restrict__ chain_base,
-                                                 const uint32_t *__restrict__ chain_len, uint32_t nchains) {
-    const uint32_t chain = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (chain >= nchains) return;
+__device__ __forceinline__ void add_block_sums(uint32_t w, uint32_t &b01, uint32_t &b23, uint32_t &b45) {
+    b01 += packed_shift_sum<0>(w, ET()) | (packed_shift_sum<1>(w, ET()) << 16);
+    b23 += packed_shift_sum<2>(w, ET()) | (packed_shift_sum<3>(w, ET()) << 16);
+    b45 += packed_shift_sum<4>(w, ET()) | (packed_shift_sum<5>(w, ET()) << 16);
+}
+
+// Rice lengths of one event for k = 0..5 (rice_coding.rs:56-58), two 16-bit fields per dword
+// (64 * 511 < 2^16, so a wave's prefix sums cannot carry between fields).
+__device__ __forceinline__ void packed_lengths(uint32_t e, uint32_t &l01, uint32_t &l23, uint32_t &l45) {
+    l01 = (e + 1u) | (((e >> 1) + 2u) << 16);
+    l23 = ((e >> 2) + 3u) | (((e >> 3) + 4u) << 16);
+    l45 = ((e >> 4) + 5u) | (((e >> 5) + 6u) << 16);
+}
+
+constexpr uint32_t SPINE_BATCH = 64;  // blocks fetched per step: lane j holds block j
+
+template <typename ET>
+__global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, uint32_t *__restrict__ block_state,
+                                              const uint32_t *__restrict__ chain_base,
+                                              const uint32_t *__restrict__ chain_len, uint32_t nchains) {
+    constexpr uint32_t DW = 64 * sizeof(ET) / 4;  // dwords per block
+    __shared__ uint32_t stage[SPINE_BATCH * DW];          // the batch's events
+    __shared__ uint32_t bsum[(SPINE_BATCH + 1) * 8];      // [block][k]: sum of the block's lengths for k = 0..5
+    __shared__ uint32_t rec[SPINE_BATCH * 8];             // [block][k]: state at the start of the block
+    // Workgroup w -> (context w / nplanes, plane w % nplanes): the long chains (small contexts) of all
+    // planes start first and land on different XCDs (workgroups are dealt round-robin over the XCDs).
+    if (blockIdx.x >= nchains) return;
+    const uint32_t nplanes = nchains / NCTX;
+    const uint32_t chain = (blockIdx.x % nplanes) * NCTX + blockIdx.x / nplanes;
     const uint32_t n = chain_len[chain];
     if (n == 0) return;
     const uint32_t lane = lane_id();
-    const ET *ev = sorted_e + chain_base[chain];
-    uint8_t *kout = k_sorted + chain_base[chain];
+    const uint32_t l7 = lane & 7u;
+    const uint32_t base = chain_base[chain];  // multiple of 64
+    const uint32_t nblocks = (n + 63u) >> 6;
+    const uint4 *src = reinterpret_cast<const uint4 *>(sorted_e + base);  // block b = DW/4 uint4 at b*DW/4
+    uint4 *states = reinterpret_cast<uint4 *>(block_state) + (uint64_t)(base >> 6) * 2;
 
-    uint32_t S0 = 0, S1 = 0, S2 = 0, S3 = 0, S4 = 0, S5 = 0;  // wave-uniform
-    uint32_t e_next = lane < n ? (uint32_t)ev[lane] : 0;
-    for (uint32_t g = 0; g < n; g += 64) {
-        const bool valid = g + lane < n;
-        const uint32_t e = e_next;
-        if (g + 64 < n) e_next = (g + 64 + lane < n) ? (uint32_t)ev[g + 64 + lane] : 0;
-        // Rice lengths (rice_coding.rs:56-58), two 16-bit sums per dword: 64 * 512 < 2^15.
-        const uint32_t l0 = valid ? e + 1 : 0, l1 = valid ? (e >> 1) + 2 : 0, l2 = valid ? (e >> 2) + 3 : 0;
-        const uint32_t l3 = valid ? (e >> 3) + 4 : 0, l4 = valid ? (e >> 4) + 5 : 0, l5 = valid ? (e >> 5) + 6 : 0;
-        const uint32_t p01 = wave_incl_scan(l0 | (l1 << 16));
-        const uint32_t p23 = wave_incl_scan(l2 | (l3 << 16));
-        const uint32_t p45 = wave_incl_scan(l4 | (l5 << 16));
-        const uint32_t P0 = p01 & 0xFFFF, P1 = p01 >> 16, P2 = p23 & 0xFFFF, P3 = p23 >> 16;
-        const uint32_t P4 = p45 & 0xFFFF, P5 = p45 >> 16;
-        uint32_t kk = 0;
-        uint32_t lo = 0;
-        while (true) {
-            const uint32_t T0 = S0 + P0, T1 = S1 + P1, T2 = S2 + P2, T3 = S3 + P3, T4 = S4 + P4, T5 = S5 + P5;
-            const uint32_t mn = min(min(min(T0, T1), min(T2, T3)), min(T4, T5));
-            // state BEFORE this lane's event -> its k (get_k precedes update, compression.rs:127,139)
-            const uint32_t X0 = T0 - l0, X1 = T1 - l1, X2 = T2 - l2, X3 = T3 - l3, X4 = T4 - l4, X5 = T5 - l5;
-            uint32_t key = min(min(min((X0 << 3) | 7u, (X1 << 3) | 6u), min((X2 << 3) | 5u, (X3 << 3) | 4u)),
-                               min((X4 << 3) | 3u, (X5 << 3) | 2u));
-            const uint32_t cand = 7u - (key & 7u);
-            const bool live = valid && lane >= lo;
-            const uint64_t hm = __ballot(live && mn > 1024u);
-            if (hm == 0) {
-                if (live) kk = cand;
-                S0 += readlane(P0, 63); S1 += readlane(P1, 63); S2 += readlane(P2, 63);
-                S3 += readlane(P3, 63); S4 += readlane(P4, 63); S5 += readlane(P5, 63);
-                break;
-            }
-            const uint32_t f = (uint32_t)__ffsll((long long)hm) - 1u;
-            if (live && lane <= f) kk = cand;
-            const uint32_t f0 = readlane(P0, f), f1 = readlane(P1, f), f2 = readlane(P2, f);
-            const uint32_t f3 = readlane(P3, f), f4 = readlane(P4, f), f5 = readlane(P5, f);
-            // S <- ((S + P(f)) >> 1) - P(f): later lanes add their own P(t) >= P(f) back (mod 2^32)
-            S0 = ((S0 + f0) >> 1) - f0; S1 = ((S1 + f1) >> 1) - f1; S2 = ((S2 + f2) >> 1) - f2;
-            S3 = ((S3 + f3) >> 1) - f3; S4 = ((S4 + f4) >> 1) - f4; S5 = ((S5 + f5) >> 1) - f5;
-            lo = f + 1;
-            if (lo >= 64) {
-                S0 += readlane(P0, 63); S1 += readlane(P1, 63); S2 += readlane(P2, 63);
-                S3 += readlane(P3, 63); S4 += readlane(P4, 63); S5 += readlane(P5, 63);
-                break;
-            }
-        }
-        if (valid) kout[g + lane] = (uint8_t)kk;
+    uint4 buf[DW / 4];
+    if (lane < nblocks) {
+#pragma unroll
+        for (uint32_t q = 0; q < DW / 4; q++) buf[q] = src[(uint64_t)lane * (DW / 4) + q];
     }
+    if (lane < 8) bsum[SPINE_BATCH * 8 + lane] = 0;  // read (and ignored) by the look-ahead of the last block
+    // The state lives in a VGPR: lane l holds S[l & 7] (entries 6, 7 unused).  Stepping over a block
+    // without a halving is then one LDS read, one add and one compare for all six counters.
+    uint32_t Sv = 0;
+    for (uint32_t bb = 0; bb < nblocks; bb += SPINE_BATCH) {
+        const uint32_t nb = min(SPINE_BATCH, nblocks - bb);
+        // lane j: sums of block bb + j, constant part 64 * (1 + k) included; events copied to LDS
+        if (lane < nb) {
+            uint32_t B01 = 64u * (1u | (2u << 16)), B23 = 64u * (3u | (4u << 16)), B45 = 64u * (5u | (6u << 16));
+#pragma unroll
+            for (uint32_t q = 0; q < DW / 4; q++) {
+                add_block_sums<ET>(buf[q].x, B01, B23, B45);
+                add_block_sums<ET>(buf[q].y, B01, B23, B45);
+                add_block_sums<ET>(buf[q].z, B01, B23, B45);
+                add_block_sums<ET>(buf[q].w, B01, B23, B45);
+                reinterpret_cast<uint4 *>(stage)[lane * (DW / 4) + q] = buf[q];
+            }
+            reinterpret_cast<uint4 *>(bsum)[lane * 2] = make_uint4(B01 & 0xFFFFu, B01 >> 16, B23 & 0xFFFFu, B23 >> 16);
+            reinterpret_cast<uint4 *>(bsum)[lane * 2 + 1] = make_uint4(B45 & 0xFFFFu, B45 >> 16, 0u, 0u);
+        }
+        __syncthreads();
+        // prefetch the next batch while this one is walked
+        if (bb + SPINE_BATCH + lane < nblocks) {
+#pragma unroll
+            for (uint32_t q = 0; q < DW / 4; q++) buf[q] = src[(uint64_t)(bb + SPINE_BATCH + lane) * (DW / 4) + q];
+        }
+        uint32_t Bv = bsum[l7];
+        for (uint32_t j = 0; j < nb; j++) {
+            const uint32_t Bnext = bsum[(j + 1) * 8 + l7];  // look-ahead: independent of the state
+            rec[j * 8 + l7] = Sv;                            // lanes l and l + 8 store the same value
+            const uint32_t Ev = Sv + Bv;
+            const uint32_t over = (uint32_t)__ballot(Ev > 1024u) & 0x3Fu;
+            if (over != 0x3Fu) {  // some counter still <= 1024 at the end of the block: no halving inside
+                Sv = Ev;
+                Bv = Bnext;
+                continue;
+            }
+            // a halving happens inside this block: find it with the block's per-event prefix sums
+            uint32_t S0 = readlane(Sv, 0), S1 = readlane(Sv, 1), S2 = readlane(Sv, 2);
+            uint32_t S3 = readlane(Sv, 3), S4 = readlane(Sv, 4), S5 = readlane(Sv, 5);
+            const uint32_t e = (uint32_t) reinterpret_cast<const ET *>(stage)[j * 64 + lane];
+            uint32_t l01, l23, l45;
+            packed_lengths(e, l01, l23, l45);
+            const uint32_t p01 = wave_incl_scan(l01), p23 = wave_incl_scan(l23), p45 = wave_incl_scan(l45);
+            const uint32_t P0 = p01 & 0xFFFFu, P1 = p01 >> 16, P2 = p23 & 0xFFFFu, P3 = p23 >> 16;
+            const uint32_t P4 = p45 & 0xFFFFu, P5 = p45 >> 16;
+            uint32_t lo = 0;
+            while (true) {
+                const uint32_t mn = min(min(min(S0 + P0, S1 + P1), min(S2 + P2, S3 + P3)), min(S4 + P4, S5 + P5));
+                const uint64_t hm = __ballot(lane >= lo && mn > 1024u);
+                if (hm == 0) break;
+                const uint32_t f = (uint32_t)__ffsll((long long)hm) - 1u;
+                const uint32_t f0 = readlane(P0, f), f1 = readlane(P1, f), f2 = readlane(P2, f);
+                const uint32_t f3 = readlane(P3, f), f4 = readlane(P4, f), f5 = readlane(P5, f);
+                // S <- ((S + P(f)) >> 1) - P(f): later lanes add their own P(t) >= P(f) back (mod 2^32)
+                S0 = ((S0 + f0) >> 1) - f0; S1 = ((S1 + f1) >> 1) - f1; S2 = ((S2 + f2) >> 1) - f2;
+                S3 = ((S3 + f3) >> 1) - f3; S4 = ((S4 + f4) >> 1) - f4; S5 = ((S5 + f5) >> 1) - f5;
+                lo = f + 1;
+                if (lo >= 64) break;
+                // state at the end of the block if nothing else happens; another round only if it would halve
+                const uint32_t E0 = S0 + readlane(Bv, 0), E1 = S1 + readlane(Bv, 1), E2 = S2 + readlane(Bv, 2);
+                const uint32_t E3 = S3 + readlane(Bv, 3), E4 = S4 + readlane(Bv, 4), E5 = S5 + readlane(Bv, 5);
+                if (min(min(min(E0, E1), min(E2, E3)), min(E4, E5)) <= 1024u) break;
+            }
+            // block sums are the prefix sums at lane 63
+            const uint32_t s01 = l7 == 0 ? S0 : S1, s23 = l7 == 2 ? S2 : S3, s45 = l7 == 4 ? S4 : S5;
+            Sv = (l7 < 2 ? s01 : l7 < 4 ? s23 : l7 < 6 ? s45 : 0u) + Bv;
+            Bv = Bnext;
+        }
+        __syncthreads();
+        if (lane < nb) {
+            states[(uint64_t)(bb + lane) * 2] = reinterpret_cast<const uint4 *>(rec)[lane * 2];
+            states[(uint64_t)(bb + lane) * 2 + 1] = reinterpret_cast<const uint4 *>(rec)[lane * 2 + 1];
+        }
+        __syncthreads();
+    }
+}
+
+// One wave per 64-event block (chains are 64-aligned, so a block never straddles two chains):
+// start state from k_spine, the block's in-wave prefix sums, k for every event.
+template <typename ET>
+__global__ __launch_bounds__(256) void k_assign(const ET *__restrict__ sorted_e, const uint32_t *__restrict__ block_state,
+                                                uint8_t *__restrict__ k_sorted,
+                                                const uint32_t *__restrict__ total_slots) {
+    const uint32_t lane = lane_id();
+    const uint32_t nblocks = *total_slots >> 6;
+    const uint32_t gb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (gb >= nblocks) return;
+    const uint4 *st = reinterpret_cast<const uint4 *>(block_state) + (uint64_t)gb * 2;
+    const uint4 sa = st[0], sb = st[1];
+    uint32_t S0 = sa.x, S1 = sa.y, S2 = sa.z, S3 = sa.w, S4 = sb.x, S5 = sb.y;
+    const uint32_t e = (uint32_t)sorted_e[(uint64_t)gb * 64 + lane];
+    uint32_t l01, l23, l45;
+    packed_lengths(e, l01, l23, l45);
+    const uint32_t p01 = wave_incl_scan(l01), p23 = wave_incl_scan(l23), p45 = wave_incl_scan(l45);
+    const uint32_t P0 = p01 & 0xFFFFu, P1 = p01 >> 16, P2 = p23 & 0xFFFFu, P3 = p23 >> 16;
+    const uint32_t P4 = p45 & 0xFFFFu, P5 = p45 >> 16;
+    const uint32_t l0 = l01 & 0xFFFFu, l1 = l01 >> 16, l2 = l23 & 0xFFFFu, l3 = l23 >> 16, l4 = l45 & 0xFFFFu, l5 = l45 >> 16;
+    uint32_t kk = 0, lo = 0;
+    while (true) {
+        const uint32_t T0 = S0 + P0, T1 = S1 + P1, T2 = S2 + P2, T3 = S3 + P3, T4 = S4 + P4, T5 = S5 + P5;
+        const uint32_t mn = min(min(min(T0, T1), min(T2, T3)), min(T4, T5));
+        // state BEFORE this lane's event -> its k (get_k precedes update, compression.rs:127,139)
+        const uint32_t X0 = T0 - l0, X1 = T1 - l1, X2 = T2 - l2, X3 = T3 - l3, X4 = T4 - l4, X5 = T5 - l5;
+        const uint32_t key = min(min(min((X0 << 3) | 7u, (X1 << 3) | 6u), min((X2 << 3) | 5u, (X3 << 3) | 4u)),
+                                 min((X4 << 3) | 3u, (X5 << 3) | 2u));
+        const uint32_t cand = 7u - (key & 7u);
+        const uint64_t hm = __ballot(lane >= lo && mn > 1024u);
+        if (hm == 0) {
+            if (lane >= lo) kk = cand;
+            break;
+        }
+        const uint32_t f = (uint32_t)__ffsll((long long)hm) - 1u;
+        if (lane >= lo && lane <= f) kk = cand;
+        const uint32_t f0 = readlane(P0, f), f1 = readlane(P1, f), f2 = readlane(P2, f);
+        const uint32_t f3 = readlane(P3, f), f4 = readlane(P4, f), f5 = readlane(P5, f);
+        S0 = ((S0 + f0) >> 1) - f0; S1 = ((S1 + f1) >> 1) - f1; S2 = ((S2 + f2) >> 1) - f2;
+        S3 = ((S3 + f3) >> 1) - f3; S4 = ((S4 + f4) >> 1) - f4; S5 = ((S5 + f5) >> 1) - f5;
+        lo = f + 1;
+        if (lo >= 64) break;
+    }
+    k_sorted[(uint64_t)gb * 64 + lane] = (uint8_t)kk;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -686,16 +822,22 @@ template void launch_scatter<int16_t, uint16_t>(hipStream_t, const int16_t *, co
                                                 uint16_t *, uint32_t *, const Geometry &);
 
 template <typename ET>
-void launch_resolve(hipStream_t s, const ET *sorted_e, uint8_t *k_sorted, const uint32_t *chain_base,
-                    const uint32_t *chain_len, const Geometry &g) {
+void launch_resolve(hipStream_t s, ET *sorted_e, uint8_t *k_sorted, uint32_t *block_state,
+                    const uint32_t *chain_base, const uint32_t *chain_len, const uint32_t *total_slots,
+                    const Geometry &g) {
     const uint32_t nchains = g.nplanes * NCTX;
-    hipLaunchKernelGGL((k_resolve<ET>), dim3(cdiv(nchains, 4)), dim3(256), 0, s, sorted_e, k_sorted, chain_base,
+    hipLaunchKernelGGL((k_zero_padding<ET>), dim3(cdiv(nchains, 256)), dim3(256), 0, s, sorted_e, chain_base,
                        chain_len, nchains);
+    hipLaunchKernelGGL((k_spine<ET>), dim3(nchains), dim3(64), 0, s, (const ET *)sorted_e, block_state, chain_base,
+                       chain_len, nchains);
+    const uint32_t max_blocks = max_event_blocks(g);
+    hipLaunchKernelGGL((k_assign<ET>), dim3(cdiv(max_blocks, 4)), dim3(256), 0, s, (const ET *)sorted_e,
+                       (const uint32_t *)block_state, k_sorted, total_slots);
 }
-template void launch_resolve<uint8_t>(hipStream_t, const uint8_t *, uint8_t *, const uint32_t *, const uint32_t *,
-                                      const Geometry &);
-template void launch_resolve<uint16_t>(hipStream_t, const uint16_t *, uint8_t *, const uint32_t *,
-                                       const uint32_t *, const Geometry &);
+template void launch_resolve<uint8_t>(hipStream_t, uint8_t *, uint8_t *, uint32_t *, const uint32_t *,
+                                      const uint32_t *, const uint32_t *, const Geometry &);
+template void launch_resolve<uint16_t>(hipStream_t, uint16_t *, uint8_t *, uint32_t *, const uint32_t *,
+                                       const uint32_t *, const uint32_t *, const Geometry &);
 
 template <typename T>
 void launch_lengths(hipStream_t s, const T *planes, const uint32_t *slot_of, const uint8_t *k_sorted,

@@ -36,8 +36,8 @@ struct felics_ctx {
     float stage_ms[ST_COUNT] = {};
 
     // workspace (HBM), grown on demand and kept between calls
-    DevBuf in, planes, counts, chain_len, chain_base, scalars, sorted_e, k_sorted, block_state, slot_of, tile_bits,
-        tile_bitoff, image_bytes, image_off, out;
+    DevBuf in, planes, counts, chain_len, chain_base, scalars, sorted_e, pix_of, k_map, block_state, group_bits,
+        tile_bits, tile_bitoff, image_bytes, image_off, out;
     std::vector<uint64_t> h_sizes;  // image_bytes[n] followed by image_off[n+1]
 };
 
@@ -119,9 +119,10 @@ int analyse(felics_ctx *ctx, const Geometry &g, const T *d_planes) {
     if ((rc = reserve(ctx, ctx->scalars, 64)) != 0) return rc;
     const size_t slots = (size_t)max_event_slots(g);
     if ((rc = reserve(ctx, ctx->sorted_e, slots * sizeof(ET) + SORTED_PAD)) != 0) return rc;
-    if ((rc = reserve(ctx, ctx->k_sorted, slots)) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->pix_of, slots * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->k_map, nsamples + STAGE_PAD)) != 0) return rc;
     if ((rc = reserve(ctx, ctx->block_state, (size_t)max_event_blocks(g) * 32)) != 0) return rc;
-    if ((rc = reserve(ctx, ctx->slot_of, nsamples * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->group_bits, (size_t)g.nplanes * g.pack_tiles * PACK_THREADS * 2)) != 0) return rc;
     if ((rc = reserve(ctx, ctx->tile_bits, (size_t)g.nplanes * g.pack_tiles * 4)) != 0) return rc;
     if ((rc = reserve(ctx, ctx->tile_bitoff, (size_t)g.nplanes * g.pack_tiles * 8)) != 0) return rc;
     if ((rc = reserve(ctx, ctx->image_bytes, (size_t)g.nimages * 8)) != 0) return rc;
@@ -141,16 +142,16 @@ int analyse(felics_ctx *ctx, const Geometry &g, const T *d_planes) {
     }
     {
         StageTimer t(ctx, ST_SCATTER);
-        launch_scatter<T, ET>(s, d_planes, counts, chain_base, (ET *)ctx->sorted_e.p, (uint32_t *)ctx->slot_of.p, g);
+        launch_scatter<T, ET>(s, d_planes, counts, chain_base, (ET *)ctx->sorted_e.p, (uint32_t *)ctx->pix_of.p, g);
     }
     {
         StageTimer t(ctx, ST_RESOLVE);
-        launch_resolve<ET>(s, (ET *)ctx->sorted_e.p, (uint8_t *)ctx->k_sorted.p, (uint32_t *)ctx->block_state.p,
-                           chain_base, chain_len, (const uint32_t *)ctx->scalars.p, g);
+        launch_resolve<ET>(s, (ET *)ctx->sorted_e.p, (uint32_t *)ctx->pix_of.p, (uint8_t *)ctx->k_map.p,
+                           (uint32_t *)ctx->block_state.p, chain_base, chain_len, (const uint32_t *)ctx->scalars.p, g);
     }
     {
         StageTimer t(ctx, ST_LENGTHS);
-        launch_lengths<T>(s, d_planes, (const uint32_t *)ctx->slot_of.p, (const uint8_t *)ctx->k_sorted.p,
+        launch_lengths<T>(s, d_planes, (const uint8_t *)ctx->k_map.p, (uint16_t *)ctx->group_bits.p,
                           (uint32_t *)ctx->tile_bits.p, g);
     }
     {
@@ -176,7 +177,7 @@ int emit(felics_ctx *ctx, const Geometry &g, const T *d_planes, uint8_t *d_out) 
     }
     {
         StageTimer t(ctx, ST_PACK);
-        launch_pack<T>(s, d_planes, (const uint32_t *)ctx->slot_of.p, (const uint8_t *)ctx->k_sorted.p,
+        launch_pack<T>(s, d_planes, (const uint8_t *)ctx->k_map.p, (const uint16_t *)ctx->group_bits.p,
                        (const uint64_t *)ctx->tile_bitoff.p, (const uint32_t *)ctx->tile_bits.p,
                        (const uint64_t *)ctx->image_off.p, d_out, g);
     }
@@ -328,7 +329,7 @@ void felics_ctx_destroy(felics_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->in, &ctx->planes, &ctx->counts, &ctx->chain_len, &ctx->chain_base, &ctx->scalars,
-                      &ctx->sorted_e, &ctx->k_sorted, &ctx->block_state, &ctx->slot_of, &ctx->tile_bits, &ctx->tile_bitoff,
+                      &ctx->sorted_e, &ctx->pix_of, &ctx->k_map, &ctx->block_state, &ctx->group_bits, &ctx->tile_bits, &ctx->tile_bitoff,
                       &ctx->image_bytes, &ctx->image_off, &ctx->out};
     for (DevBuf *b : bufs) release(*b);
     for (int i = 0; i < ST_COUNT; i++)

@@ -41,7 +41,7 @@ void launch_offsets(hipStream_t s, uint32_t *counts, uint32_t *chain_len, uint32
 
 template <typename T, typename ET>
 void launch_scatter(hipStream_t s, const T *planes, const uint32_t *tile_off, const uint32_t *chain_base,
-                    ET *sorted_e, uint32_t *slot_of, const Geometry &g);
+                    ET *sorted_e, uint32_t *pix_of, const Geometry &g);
 
 // Chains are padded to whole 64-event blocks: upper bounds of the slot / block counts of a pass.
 inline uint64_t max_event_slots(const Geometry &g) {
@@ -51,15 +51,17 @@ inline uint32_t max_event_blocks(const Geometry &g) { return (uint32_t)(max_even
 
 // sorted_e needs max_event_slots() elements plus SORTED_PAD bytes (the spine reads 64 blocks ahead)
 constexpr size_t SORTED_PAD = 64 * 64 * 2 + 256;
+// k_map / plane buffers are read in whole 16-byte chunks by the tile staging
+constexpr size_t STAGE_PAD = 64;
 
 template <typename ET>
-void launch_resolve(hipStream_t s, ET *sorted_e, uint8_t *k_sorted, uint32_t *block_state,
+void launch_resolve(hipStream_t s, ET *sorted_e, uint32_t *pix_of, uint8_t *k_map, uint32_t *block_state,
                     const uint32_t *chain_base, const uint32_t *chain_len, const uint32_t *total_slots,
                     const Geometry &g);
 
 template <typename T>
-void launch_lengths(hipStream_t s, const T *planes, const uint32_t *slot_of, const uint8_t *k_sorted,
-                    uint32_t *tile_bits, const Geometry &g);
+void launch_lengths(hipStream_t s, const T *planes, const uint8_t *k_map, uint16_t *group_bits, uint32_t *tile_bits,
+                    const Geometry &g);
 
 void launch_bitscan(hipStream_t s, const uint32_t *tile_bits, uint64_t *tile_bitoff, uint64_t *image_bytes,
                     uint64_t *image_off, const Geometry &g);
@@ -67,7 +69,7 @@ void launch_bitscan(hipStream_t s, const uint32_t *tile_bits, uint64_t *tile_bit
 void launch_zero_streams(hipStream_t s, uint32_t *out, const uint64_t *image_off, const Geometry &g);
 
 template <typename T>
-void launch_pack(hipStream_t s, const T *planes, const uint32_t *slot_of, const uint8_t *k_sorted,
+void launch_pack(hipStream_t s, const T *planes, const uint8_t *k_map, const uint16_t *group_bits,
                  const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint64_t *image_off, uint8_t *out,
                  const Geometry &g);
 

@@ -218,27 +218,32 @@ __global__ __launch_bounds__(1024) void k_chain_bases(const uint32_t *__restrict
 }
 
 // Zero the padding events at the end of every chain's last block (value 0 adds nothing to a
-// block's sum of e >> k, and nothing after a chain's last real event is ever used).
+// block's sum of e >> k, and nothing after a chain's last real event is ever used) and mark the
+// padding slots as belonging to no pixel.
 template <typename ET>
-__global__ void k_zero_padding(ET *__restrict__ sorted_e, const uint32_t *__restrict__ chain_base,
-                               const uint32_t *__restrict__ chain_len, uint32_t nchains) {
+__global__ void k_zero_padding(ET *__restrict__ sorted_e, uint32_t *__restrict__ pix_of,
+                               const uint32_t *__restrict__ chain_base, const uint32_t *__restrict__ chain_len,
+                               uint32_t nchains) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchains) return;
     const uint32_t n = chain_len[c], base = chain_base[c];
-    for (uint32_t i = n; i < ((n + 63u) & ~63u); i++) sorted_e[base + i] = 0;
+    for (uint32_t i = n; i < ((n + 63u) & ~63u); i++) {
+        sorted_e[base + i] = 0;
+        pix_of[base + i] = 0xFFFFFFFFu;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
 // scatter: stable partition of events by context.  One wave per tile walks its pixels in
 // raster order, 64 at a time; lanes that hold the same context rank themselves with a ballot.
-// sorted_e[slot] = value to Rice-code; slot_of[plane*npix + i] = slot (events only).
+// sorted_e[slot] = value to Rice-code; pix_of[slot] = plane*npix + i, the pixel the event came from.
 // ------------------------------------------------------------------------------------------
 
 template <typename T, typename ET>
 __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
                                                  const uint32_t *__restrict__ tile_off,
                                                  const uint32_t *__restrict__ chain_base,
-                                                 ET *__restrict__ sorted_e, uint32_t *__restrict__ slot_of,
+                                                 ET *__restrict__ sorted_e, uint32_t *__restrict__ pix_of,
                                                  uint32_t W, uint32_t npix, uint32_t ntiles) {
     __shared__ uint32_t runs[4][NCTX];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
     }
     __builtin_amdgcn_wave_barrier();
     const T *pl = planes + (uint64_t)plane * npix;
-    uint32_t *slots = slot_of + (uint64_t)plane * npix;
+    const uint32_t plane_first = plane * npix;
     const uint32_t begin = tile * SORT_TILE;
     const uint32_t end = min(begin + SORT_TILE, npix);
     const uint64_t lt = lanemask_lt();
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
         }
         if (ev) {
             sorted_e[dest] = (ET)e;
-            slots[i] = dest;
+            pix_of[dest] = plane_first + i;
         }
     }
 }
@@ -443,10 +448,11 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
 }
 
 // One wave per 64-event block (chains are 64-aligned, so a block never straddles two chains):
-// start state from k_spine, the block's in-wave prefix sums, k for every event.
+// start state from k_spine, the block's in-wave prefix sums, k for every event, stored at the
+// event's pixel (k_map is in raster order, one byte per sample; only event pixels are written).
 template <typename ET>
 __global__ __launch_bounds__(256) void k_assign(const ET *__restrict__ sorted_e, const uint32_t *__restrict__ block_state,
-                                                uint8_t *__restrict__ k_sorted,
+                                                const uint32_t *__restrict__ pix_of, uint8_t *__restrict__ k_map,
                                                 const uint32_t *__restrict__ total_slots) {
     const uint32_t lane = lane_id();
     const uint32_t nblocks = *total_slots >> 6;
@@ -485,7 +491,8 @@ __global__ __launch_bounds__(256) void k_assign(const ET *__restrict__ sorted_e,
         lo = f + 1;
         if (lo >= 64) break;
     }
-    k_sorted[(uint64_t)gb * 64 + lane] = (uint8_t)kk;
+    const uint32_t pix = pix_of[(uint64_t)gb * 64 + lane];
+    if (pix != 0xFFFFFFFFu) k_map[pix] = (uint8_t)kk;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -519,49 +526,138 @@ __device__ __forceinline__ uint32_t code_length(const PixelClass &pc, uint32_t k
 }
 
 // ------------------------------------------------------------------------------------------
-// lengths: bits per PACK_TILE pixels.  Thread t owns PACK_PER_THREAD consecutive pixels.
-// Plane 0 of an image also carries the 112 header bits; pixels 0 and 1 are raw 32-bit values
-// (compression.rs:105-106).
+// Tile staging shared by lengths / pack.  A tile is PACK_TILE consecutive pixels of one plane;
+// thread t owns the PACK_PER_THREAD consecutive pixels first = tile*PACK_TILE + t*PACK_PER_THREAD.
+// The tile's pixels, the span one row above it and its k bytes are copied into LDS with wide
+// coalesced loads; each thread then pulls its 16 pixels into registers with 16-byte LDS reads.
+// Interior pixels (x > 0, y > 0: left and above neighbours) are served from those registers; the
+// few pixels on the first row / first column take the general neighbour rule from global memory.
 // ------------------------------------------------------------------------------------------
 
+constexpr uint32_t STAGE_LEAD = 16;  // elements kept in front of the tile (the left neighbours), keeps 16-B alignment
+
 template <typename T>
-__device__ __forceinline__ uint32_t thread_bits(const T *__restrict__ pl, const uint32_t *__restrict__ slots,
-                                                const uint8_t *__restrict__ k_sorted, uint32_t first,
-                                                uint32_t end, uint32_t W) {
-    uint32_t bits = 0;
-    if (first >= end) return 0;
-    Coord xy;
-    xy.set(first, W);
-    for (uint32_t i = first; i < end; i++) {
-        if (i < 2) {
-            bits += 32;
+struct TileLDS {
+    alignas(16) T cur[STAGE_LEAD + PACK_TILE];  // cur[STAGE_LEAD + j] = pixel tile_first + j
+    alignas(16) T up[PACK_TILE + 16];            // up[j] = pixel tile_first - W + j
+    alignas(16) uint8_t kq[PACK_TILE];           // k of pixel tile_first + j
+};
+
+// lds[j] = g[first + j] for j in [0, count), indices outside [0, limit) skipped; 16-byte copies
+// when the global side is 16-byte aligned.
+template <typename U>
+__device__ __forceinline__ void stage_span(U *lds, const U *__restrict__ g, int64_t first, uint32_t count,
+                                           uint32_t limit) {
+    constexpr uint32_t EPC = 16 / sizeof(U);  // elements per 16-byte chunk
+    const bool aligned = ((reinterpret_cast<uintptr_t>(g) + (uint64_t)first * sizeof(U)) & 15u) == 0;
+    const uint32_t nchunks = (count + EPC - 1) / EPC;
+    for (uint32_t c = threadIdx.x; c < nchunks; c += PACK_THREADS) {
+        const int64_t g0 = first + (int64_t)c * EPC;
+        if (aligned && g0 >= 0 && g0 + EPC <= (int64_t)limit) {
+            reinterpret_cast<uint4 *>(lds)[c] = *reinterpret_cast<const uint4 *>(g + g0);
         } else {
-            PixelClass pc = classify(pl, i, xy.x, xy.y, W);
-            uint32_t k = 0;
-            if (pc.cls != CLS_IN) k = k_sorted[slots[i]];
-            bits += code_length(pc, k);
+#pragma unroll
+            for (uint32_t e = 0; e < EPC; e++) {
+                const int64_t gi = g0 + e;
+                if (gi >= 0 && gi < (int64_t)limit && c * EPC + e < count) lds[c * EPC + e] = g[gi];
+            }
         }
-        xy.advance(1, W);
     }
-    return bits;
 }
 
 template <typename T>
-__global__ __launch_bounds__(PACK_THREADS) void k_lengths(const T *__restrict__ planes,
-                                                          const uint32_t *__restrict__ slot_of,
-                                                          const uint8_t *__restrict__ k_sorted,
-                                                          uint32_t *__restrict__ tile_bits, uint32_t W,
-                                                          uint32_t npix, uint32_t ntiles, uint32_t planes_per_image) {
+__device__ __forceinline__ void stage_tile(TileLDS<T> &t, const T *__restrict__ pl, const uint8_t *__restrict__ kpl,
+                                           uint32_t tile_first, uint32_t W, uint32_t npix) {
+    stage_span<T>(t.cur, pl, (int64_t)tile_first - STAGE_LEAD, STAGE_LEAD + PACK_TILE, npix);
+    stage_span<T>(t.up, pl, (int64_t)tile_first - W, PACK_TILE + 16, npix);
+    stage_span<uint8_t>(t.kq, kpl, (int64_t)tile_first, PACK_TILE, npix);
+}
+
+__device__ __forceinline__ int sample_at(const uint32_t *w, uint32_t j, uint8_t) {
+    return (int)((w[j >> 2] >> (8u * (j & 3u))) & 0xFFu);
+}
+__device__ __forceinline__ int sample_at(const uint32_t *w, uint32_t j, int16_t) {
+    return (int)(int16_t)(w[j >> 1] >> (16u * (j & 1u)));
+}
+
+// Calls f(i, raw, raw_value, pc, k) for every pixel i of this thread's group, in raster order.
+// raw == true for pixels 0 and 1 of the plane (stored as 32-bit values, compression.rs:105-106).
+template <typename T, typename F>
+__device__ __forceinline__ void walk_group(const TileLDS<T> &t, const T *__restrict__ pl, uint32_t first, uint32_t end,
+                                           uint32_t W, F &&f) {
+    if (first >= end) return;
+    constexpr uint32_t NW = PACK_PER_THREAD * sizeof(T) / 4;  // dwords holding the group's pixels
+    const uint32_t off = threadIdx.x * PACK_PER_THREAD;
+    uint32_t cw[NW], uw[NW], kw[4];
+#pragma unroll
+    for (uint32_t q = 0; q < NW / 4; q++) {
+        const uint4 a = reinterpret_cast<const uint4 *>(t.cur + STAGE_LEAD + off)[q];
+        const uint4 b = reinterpret_cast<const uint4 *>(t.up + off)[q];
+        cw[4 * q] = a.x; cw[4 * q + 1] = a.y; cw[4 * q + 2] = a.z; cw[4 * q + 3] = a.w;
+        uw[4 * q] = b.x; uw[4 * q + 1] = b.y; uw[4 * q + 2] = b.z; uw[4 * q + 3] = b.w;
+    }
+    {
+        const uint4 c = *reinterpret_cast<const uint4 *>(t.kq + off);
+        kw[0] = c.x; kw[1] = c.y; kw[2] = c.z; kw[3] = c.w;
+    }
+    int left = (int)t.cur[STAGE_LEAD + off - 1];
+    Coord xy;
+    xy.set(first, W);
+#pragma unroll
+    for (uint32_t j = 0; j < PACK_PER_THREAD; j++) {
+        const uint32_t i = first + j;
+        const int p = sample_at(cw, j, T());
+        if (i < end) {
+            const uint32_t k = (kw[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
+            if (i < 2) {
+                f(i, true, (uint32_t)p, PixelClass{0, 0, 0}, 0u);
+            } else if (xy.x > 0 && xy.y > 0) {
+                const int above = sample_at(uw, j, T());
+                const int H = max(left, above), L = min(left, above);
+                PixelClass pc;
+                pc.ctx = (uint32_t)(H - L);
+                pc.cls = p < L ? CLS_BELOW : (p > H ? CLS_ABOVE : CLS_IN);
+                pc.val = p < L ? (uint32_t)(L - p - 1) : (p > H ? (uint32_t)(p - H - 1) : (uint32_t)(p - L));
+                f(i, false, 0u, pc, k);
+            } else {
+                f(i, false, 0u, classify(pl, i, xy.x, xy.y, W), k);
+            }
+        }
+        left = p;
+        if (++xy.x == W) {
+            xy.x = 0;
+            xy.y++;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// lengths: bits of every 16-pixel group (group_bits, u16) and of every tile (tile_bits).
+// Plane 0 of an image also carries the 112 header bits.
+// ------------------------------------------------------------------------------------------
+
+template <typename T>
+__global__ __launch_bounds__(PACK_THREADS) void k_lengths(const T *__restrict__ planes, const uint8_t *__restrict__ k_map,
+                                                          uint16_t *__restrict__ group_bits,
+                                                          uint32_t *__restrict__ tile_bits, uint32_t W, uint32_t npix,
+                                                          uint32_t ntiles, uint32_t planes_per_image) {
+    __shared__ TileLDS<T> tl;
     __shared__ uint32_t wsum[PACK_THREADS / 64];
     const uint32_t tile = blockIdx.x, plane = blockIdx.y;
     const T *pl = planes + (uint64_t)plane * npix;
-    const uint32_t *slots = slot_of + (uint64_t)plane * npix;
-    const uint32_t first = tile * PACK_TILE + threadIdx.x * PACK_PER_THREAD;
-    const uint32_t end = min(min(first + PACK_PER_THREAD, (tile + 1) * PACK_TILE), npix);
-    uint32_t bits = thread_bits(pl, slots, k_sorted, first, end, W);
+    const uint32_t tile_first = tile * PACK_TILE;
+    stage_tile(tl, pl, k_map + (uint64_t)plane * npix, tile_first, W, npix);
+    __syncthreads();
+    const uint32_t first = tile_first + threadIdx.x * PACK_PER_THREAD;
+    const uint32_t end = min(tile_first + PACK_TILE, npix);
+    uint32_t bits = 0;
+    walk_group(tl, pl, first, end, W, [&](uint32_t, bool raw, uint32_t, const PixelClass &pc, uint32_t k) {
+        bits += raw ? 32u : code_length(pc, k);
+    });
     if (npix == 1 && first == 0) bits += 32;  // 1x1: second raw value is a literal 0 (compression.rs:99-103)
     if (tile == 0 && threadIdx.x == 0 && (plane % planes_per_image) == 0) bits += 8 * 14;  // header
-    uint32_t inc = wave_incl_scan(bits);
+    group_bits[((uint64_t)plane * ntiles + tile) * PACK_THREADS + threadIdx.x] = (uint16_t)bits;
+    const uint32_t inc = wave_incl_scan(bits);
     if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -699,30 +795,29 @@ __device__ __forceinline__ void put_pixel(LaneBits &bw, const PixelClass &pc, ui
 }
 
 template <typename T>
-__global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ planes,
-                                                       const uint32_t *__restrict__ slot_of,
-                                                       const uint8_t *__restrict__ k_sorted,
+__global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ planes, const uint8_t *__restrict__ k_map,
+                                                       const uint16_t *__restrict__ group_bits,
                                                        const uint64_t *__restrict__ tile_bitoff,
                                                        const uint32_t *__restrict__ tile_bits,
                                                        const uint64_t *__restrict__ image_off,
                                                        uint8_t *__restrict__ out, uint32_t W, uint32_t H,
                                                        uint32_t npix, uint32_t ntiles, uint32_t planes_per_image,
                                                        uint32_t color, uint32_t depth) {
+    __shared__ TileLDS<T> tl;
     __shared__ uint32_t win[PACK_WIN_WORDS];
     __shared__ uint32_t wsum[PACK_THREADS / 64];
     const uint32_t tile = blockIdx.x, plane = blockIdx.y;
     const uint32_t img = plane / planes_per_image;
     const bool first_plane = (plane % planes_per_image) == 0;
     const T *pl = planes + (uint64_t)plane * npix;
-    const uint32_t *slots = slot_of + (uint64_t)plane * npix;
-    const uint32_t first = tile * PACK_TILE + threadIdx.x * PACK_PER_THREAD;
-    const uint32_t end = min(min(first + PACK_PER_THREAD, (tile + 1) * PACK_TILE), npix);
+    const uint32_t tile_first = tile * PACK_TILE;
+    const uint32_t first = tile_first + threadIdx.x * PACK_PER_THREAD;
+    const uint32_t end = min(tile_first + PACK_TILE, npix);
     const bool has_header = tile == 0 && threadIdx.x == 0 && first_plane;
 
-    // this thread's bit offset inside the tile
-    uint32_t bits = thread_bits(pl, slots, k_sorted, first, end, W);
-    if (npix == 1 && first == 0) bits += 32;
-    if (has_header) bits += 8 * 14;
+    stage_tile(tl, pl, k_map + (uint64_t)plane * npix, tile_first, W, npix);
+    // this thread's bit offset inside the tile: scan of the group sizes k_lengths left behind
+    const uint32_t bits = group_bits[((uint64_t)plane * ntiles + tile) * PACK_THREADS + threadIdx.x];
     const uint32_t inc = wave_incl_scan(bits);
     if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
     __syncthreads();
@@ -750,20 +845,14 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ pla
                 bw.put(W, 32);
                 bw.put(H, 32);
             }
-            Coord xy;
-            xy.set(first, W);
-            for (uint32_t i = first; i < end; i++) {
-                if (i < 2) {
-                    bw.put((uint32_t)(int32_t)pl[i], 32);  // write_signed(32, p)
+            walk_group(tl, pl, first, end, W, [&](uint32_t, bool raw, uint32_t rv, const PixelClass &pc, uint32_t k) {
+                if (raw) {
+                    bw.put(rv, 32);  // write_signed(32, p): sign-extended sample
                     if (npix == 1) bw.put(0u, 32);
                 } else {
-                    PixelClass pc = classify(pl, i, xy.x, xy.y, W);
-                    uint32_t k = 0;
-                    if (pc.cls != CLS_IN) k = k_sorted[slots[i]];
                     put_pixel(bw, pc, k);
                 }
-                xy.advance(1, W);
-            }
+            });
             bw.finish();
         }
         __syncthreads();
@@ -812,9 +901,9 @@ void launch_offsets(hipStream_t s, uint32_t *counts, uint32_t *chain_len, uint32
 
 template <typename T, typename ET>
 void launch_scatter(hipStream_t s, const T *planes, const uint32_t *tile_off, const uint32_t *chain_base,
-                    ET *sorted_e, uint32_t *slot_of, const Geometry &g) {
+                    ET *sorted_e, uint32_t *pix_of, const Geometry &g) {
     hipLaunchKernelGGL((k_scatter<T, ET>), dim3(cdiv(g.sort_tiles, 4), g.nplanes), dim3(256), 0, s, planes,
-                       tile_off, chain_base, sorted_e, slot_of, g.W, g.npix, g.sort_tiles);
+                       tile_off, chain_base, sorted_e, pix_of, g.W, g.npix, g.sort_tiles);
 }
 template void launch_scatter<uint8_t, uint8_t>(hipStream_t, const uint8_t *, const uint32_t *, const uint32_t *,
                                                uint8_t *, uint32_t *, const Geometry &);
@@ -822,32 +911,32 @@ template void launch_scatter<int16_t, uint16_t>(hipStream_t, const int16_t *, co
                                                 uint16_t *, uint32_t *, const Geometry &);
 
 template <typename ET>
-void launch_resolve(hipStream_t s, ET *sorted_e, uint8_t *k_sorted, uint32_t *block_state,
+void launch_resolve(hipStream_t s, ET *sorted_e, uint32_t *pix_of, uint8_t *k_map, uint32_t *block_state,
                     const uint32_t *chain_base, const uint32_t *chain_len, const uint32_t *total_slots,
                     const Geometry &g) {
     const uint32_t nchains = g.nplanes * NCTX;
-    hipLaunchKernelGGL((k_zero_padding<ET>), dim3(cdiv(nchains, 256)), dim3(256), 0, s, sorted_e, chain_base,
+    hipLaunchKernelGGL((k_zero_padding<ET>), dim3(cdiv(nchains, 256)), dim3(256), 0, s, sorted_e, pix_of, chain_base,
                        chain_len, nchains);
     hipLaunchKernelGGL((k_spine<ET>), dim3(nchains), dim3(64), 0, s, (const ET *)sorted_e, block_state, chain_base,
                        chain_len, nchains);
     const uint32_t max_blocks = max_event_blocks(g);
     hipLaunchKernelGGL((k_assign<ET>), dim3(cdiv(max_blocks, 4)), dim3(256), 0, s, (const ET *)sorted_e,
-                       (const uint32_t *)block_state, k_sorted, total_slots);
+                       (const uint32_t *)block_state, (const uint32_t *)pix_of, k_map, total_slots);
 }
-template void launch_resolve<uint8_t>(hipStream_t, uint8_t *, uint8_t *, uint32_t *, const uint32_t *,
+template void launch_resolve<uint8_t>(hipStream_t, uint8_t *, uint32_t *, uint8_t *, uint32_t *, const uint32_t *,
                                       const uint32_t *, const uint32_t *, const Geometry &);
-template void launch_resolve<uint16_t>(hipStream_t, uint16_t *, uint8_t *, uint32_t *, const uint32_t *,
+template void launch_resolve<uint16_t>(hipStream_t, uint16_t *, uint32_t *, uint8_t *, uint32_t *, const uint32_t *,
                                        const uint32_t *, const uint32_t *, const Geometry &);
 
 template <typename T>
-void launch_lengths(hipStream_t s, const T *planes, const uint32_t *slot_of, const uint8_t *k_sorted,
-                    uint32_t *tile_bits, const Geometry &g) {
-    hipLaunchKernelGGL((k_lengths<T>), dim3(g.pack_tiles, g.nplanes), dim3(PACK_THREADS), 0, s, planes, slot_of,
-                       k_sorted, tile_bits, g.W, g.npix, g.pack_tiles, g.planes_per_image);
+void launch_lengths(hipStream_t s, const T *planes, const uint8_t *k_map, uint16_t *group_bits, uint32_t *tile_bits,
+                    const Geometry &g) {
+    hipLaunchKernelGGL((k_lengths<T>), dim3(g.pack_tiles, g.nplanes), dim3(PACK_THREADS), 0, s, planes, k_map,
+                       group_bits, tile_bits, g.W, g.npix, g.pack_tiles, g.planes_per_image);
 }
-template void launch_lengths<uint8_t>(hipStream_t, const uint8_t *, const uint32_t *, const uint8_t *, uint32_t *,
+template void launch_lengths<uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, uint16_t *, uint32_t *,
                                       const Geometry &);
-template void launch_lengths<int16_t>(hipStream_t, const int16_t *, const uint32_t *, const uint8_t *, uint32_t *,
+template void launch_lengths<int16_t>(hipStream_t, const int16_t *, const uint8_t *, uint16_t *, uint32_t *,
                                       const Geometry &);
 
 void launch_bitscan(hipStream_t s, const uint32_t *tile_bits, uint64_t *tile_bitoff, uint64_t *image_bytes,
@@ -862,18 +951,16 @@ void launch_zero_streams(hipStream_t s, uint32_t *out, const uint64_t *image_off
 }
 
 template <typename T>
-void launch_pack(hipStream_t s, const T *planes, const uint32_t *slot_of, const uint8_t *k_sorted,
+void launch_pack(hipStream_t s, const T *planes, const uint8_t *k_map, const uint16_t *group_bits,
                  const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint64_t *image_off, uint8_t *out,
                  const Geometry &g) {
-    hipLaunchKernelGGL((k_pack<T>), dim3(g.pack_tiles, g.nplanes), dim3(PACK_THREADS), 0, s, planes, slot_of,
-                       k_sorted, tile_bitoff, tile_bits, image_off, out, g.W, g.H, g.npix, g.pack_tiles,
+    hipLaunchKernelGGL((k_pack<T>), dim3(g.pack_tiles, g.nplanes), dim3(PACK_THREADS), 0, s, planes, k_map,
+                       group_bits, tile_bitoff, tile_bits, image_off, out, g.W, g.H, g.npix, g.pack_tiles,
                        g.planes_per_image, g.color, g.depth);
 }
-template void launch_pack<uint8_t>(hipStream_t, const uint8_t *, const uint32_t *, const uint8_t *,
-                                   const uint64_t *, const uint32_t *, const uint64_t *, uint8_t *,
-                                   const Geometry &);
-template void launch_pack<int16_t>(hipStream_t, const int16_t *, const uint32_t *, const uint8_t *,
-                                   const uint64_t *, const uint32_t *, const uint64_t *, uint8_t *,
-                                   const Geometry &);
+template void launch_pack<uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, const uint16_t *, const uint64_t *,
+                                   const uint32_t *, const uint64_t *, uint8_t *, const Geometry &);
+template void launch_pack<int16_t>(hipStream_t, const int16_t *, const uint8_t *, const uint16_t *, const uint64_t *,
+                                   const uint32_t *, const uint64_t *, uint8_t *, const Geometry &);
 
 }  // namespace felics

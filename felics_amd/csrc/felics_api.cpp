@@ -19,26 +19,41 @@ namespace {
 enum Stage { ST_PLANES = 0, ST_HIST, ST_OFFSETS, ST_SCATTER, ST_RESOLVE, ST_LENGTHS, ST_BITSCAN, ST_ZERO, ST_PACK, ST_COUNT };
 const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "resolve", "lengths", "bitscan", "zero", "pack"};
 
+constexpr int MAX_LANES = 3;            // sub-batches in flight, one HIP stream each (ROCm maps streams onto 4 hardware queues; the caller usually owns one)
+constexpr size_t MIN_LANE_IMAGES = 8;   // below this a sub-batch does not fill the GPU
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+};
+
+// One pipeline lane: a HIP stream, its stage events and its own workspace in HBM.  The replay of the
+// Rice-parameter estimator (k_spine) is a handful of long sequential waves; with several lanes the
+// data-parallel kernels of one sub-batch run underneath the spine of another.
+struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[ST_COUNT][2] = {};
+    bool ev_used[ST_COUNT] = {};
+    hipEvent_t sized = nullptr;       // stream sizes have landed in h_sizes
+    uint64_t *h_sizes = nullptr;      // pinned: image_bytes[n] followed by image_off[n + 1]
+    size_t h_sizes_cap = 0;
+    DevBuf planes, counts, chain_len, chain_base, scalars, sorted_e, pix_of, k_map, block_state, group_bits, tile_bits,
+        tile_bitoff, image_bytes, image_off;
+    // the sub-batch in flight
+    Geometry g;
+    size_t first_image = 0;
+    const void *d_planes = nullptr;
 };
 
 }  // namespace
 
 struct felics_ctx {
     int device = -1;
-    hipStream_t stream = nullptr;
+    Lane lanes[MAX_LANES];
     std::string err;
     bool profiling = false;
-    hipEvent_t ev[ST_COUNT][2] = {};
-    bool ev_used[ST_COUNT] = {};
     float stage_ms[ST_COUNT] = {};
-
-    // workspace (HBM), grown on demand and kept between calls
-    DevBuf in, planes, counts, chain_len, chain_base, scalars, sorted_e, pix_of, k_map, block_state, group_bits,
-        tile_bits, tile_bitoff, image_bytes, image_off, out;
-    std::vector<uint64_t> h_sizes;  // image_bytes[n] followed by image_off[n+1]
+    DevBuf in, out;  // staging of the host-pointer entry points
 };
 
 namespace {
@@ -56,11 +71,17 @@ int hip_fail(felics_ctx *ctx, hipError_t e, const char *what) {
         if (e__ != hipSuccess) return hip_fail(ctx, e__, #call);    \
     } while (0)
 
+int sync_all(felics_ctx *ctx) {
+    for (Lane &l : ctx->lanes)
+        if (l.stream) HIP_TRY(ctx, hipStreamSynchronize(l.stream));
+    return FELICS_OK;
+}
+
+// Grow-only device buffer.  Callers only grow a lane's buffer while that lane is idle.
 int reserve(felics_ctx *ctx, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap) return FELICS_OK;
     if (b.p) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipFree(b.p));
+        HIP_TRY(ctx, hipFree(b.p));  // hipFree waits for the device
         b.p = nullptr;
         b.cap = 0;
     }
@@ -78,15 +99,16 @@ void release(DevBuf &b) {
 
 struct StageTimer {
     felics_ctx *ctx;
+    Lane &lane;
     int st;
-    StageTimer(felics_ctx *c, int s) : ctx(c), st(s) {
+    StageTimer(felics_ctx *c, Lane &l, int s) : ctx(c), lane(l), st(s) {
         if (ctx->profiling) {
-            (void)hipEventRecord(ctx->ev[st][0], ctx->stream);
-            ctx->ev_used[st] = true;
+            (void)hipEventRecord(lane.ev[st][0], lane.stream);
+            lane.ev_used[st] = true;
         }
     }
     ~StageTimer() {
-        if (ctx->profiling) (void)hipEventRecord(ctx->ev[st][1], ctx->stream);
+        if (ctx->profiling) (void)hipEventRecord(lane.ev[st][1], lane.stream);
     }
 };
 
@@ -108,93 +130,103 @@ void header_bytes(uint8_t *o, uint32_t w, uint32_t h, int color, int depth) {
     }
 }
 
-// Stages up to the bit scan: after this the size of every stream is known on the host.
+// Stages up to the bit scan, queued on the lane's stream; the stream sizes are copied to the
+// lane's pinned buffer and `sized` is recorded behind them.
 template <typename T, typename ET>
-int analyse(felics_ctx *ctx, const Geometry &g, const T *d_planes) {
+int analyse(felics_ctx *ctx, Lane &l) {
+    const Geometry &g = l.g;
     const size_t nsamples = (size_t)g.nplanes * g.npix;
-    int rc;
-    if ((rc = reserve(ctx, ctx->counts, (size_t)g.nplanes * g.sort_tiles * NCTX * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, ctx->chain_len, (size_t)g.nplanes * NCTX * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, ctx->chain_base, (size_t)g.nplanes * NCTX * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, ctx->scalars, 64)) != 0) return rc;
     const size_t slots = (size_t)max_event_slots(g);
-    if ((rc = reserve(ctx, ctx->sorted_e, slots * sizeof(ET) + SORTED_PAD)) != 0) return rc;
-    if ((rc = reserve(ctx, ctx->pix_of, slots * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, ctx->k_map, nsamples + STAGE_PAD)) != 0) return rc;
-    if ((rc = reserve(ctx, ctx->block_state, (size_t)max_event_blocks(g) * 32)) != 0) return rc;
-    if ((rc = reserve(ctx, ctx->group_bits, (size_t)g.nplanes * g.pack_tiles * PACK_THREADS * 2)) != 0) return rc;
-    if ((rc = reserve(ctx, ctx->tile_bits, (size_t)g.nplanes * g.pack_tiles * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, ctx->tile_bitoff, (size_t)g.nplanes * g.pack_tiles * 8)) != 0) return rc;
-    if ((rc = reserve(ctx, ctx->image_bytes, (size_t)g.nimages * 8)) != 0) return rc;
-    if ((rc = reserve(ctx, ctx->image_off, (size_t)(g.nimages + 1) * 8)) != 0) return rc;
+    int rc;
+    if ((rc = reserve(ctx, l.counts, (size_t)g.nplanes * g.sort_tiles * NCTX * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.chain_len, (size_t)g.nplanes * NCTX * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.chain_base, (size_t)g.nplanes * NCTX * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.scalars, 64)) != 0) return rc;
+    if ((rc = reserve(ctx, l.sorted_e, slots * sizeof(ET) + SORTED_PAD)) != 0) return rc;
+    if ((rc = reserve(ctx, l.pix_of, slots * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.k_map, nsamples + STAGE_PAD)) != 0) return rc;
+    if ((rc = reserve(ctx, l.block_state, (size_t)max_event_blocks(g) * 32)) != 0) return rc;
+    if ((rc = reserve(ctx, l.group_bits, (size_t)g.nplanes * g.pack_tiles * PACK_THREADS * 2)) != 0) return rc;
+    if ((rc = reserve(ctx, l.tile_bits, (size_t)g.nplanes * g.pack_tiles * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.tile_bitoff, (size_t)g.nplanes * g.pack_tiles * 8)) != 0) return rc;
+    if ((rc = reserve(ctx, l.image_bytes, (size_t)g.nimages * 8)) != 0) return rc;
+    if ((rc = reserve(ctx, l.image_off, (size_t)(g.nimages + 1) * 8)) != 0) return rc;
+    const size_t hs = (size_t)g.nimages * 2 + 1;
+    if (hs > l.h_sizes_cap) {
+        if (l.h_sizes) HIP_TRY(ctx, hipHostFree(l.h_sizes));
+        l.h_sizes = nullptr;
+        HIP_TRY(ctx, hipHostMalloc((void **)&l.h_sizes, hs * 8 + 64, hipHostMallocDefault));
+        l.h_sizes_cap = hs;
+    }
 
-    hipStream_t s = ctx->stream;
-    auto *counts = (uint32_t *)ctx->counts.p;
-    auto *chain_len = (uint32_t *)ctx->chain_len.p;
-    auto *chain_base = (uint32_t *)ctx->chain_base.p;
+    hipStream_t s = l.stream;
+    const T *d_planes = (const T *)l.d_planes;
+    auto *counts = (uint32_t *)l.counts.p;
+    auto *chain_len = (uint32_t *)l.chain_len.p;
+    auto *chain_base = (uint32_t *)l.chain_base.p;
     {
-        StageTimer t(ctx, ST_HIST);
+        StageTimer t(ctx, l, ST_HIST);
         launch_hist<T>(s, d_planes, counts, g);
     }
     {
-        StageTimer t(ctx, ST_OFFSETS);
-        launch_offsets(s, counts, chain_len, chain_base, (uint32_t *)ctx->scalars.p, g);
+        StageTimer t(ctx, l, ST_OFFSETS);
+        launch_offsets(s, counts, chain_len, chain_base, (uint32_t *)l.scalars.p, g);
     }
     {
-        StageTimer t(ctx, ST_SCATTER);
-        launch_scatter<T, ET>(s, d_planes, counts, chain_base, (ET *)ctx->sorted_e.p, (uint32_t *)ctx->pix_of.p, g);
+        StageTimer t(ctx, l, ST_SCATTER);
+        launch_scatter<T, ET>(s, d_planes, counts, chain_base, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, g);
     }
     {
-        StageTimer t(ctx, ST_RESOLVE);
-        launch_resolve<ET>(s, (ET *)ctx->sorted_e.p, (uint32_t *)ctx->pix_of.p, (uint8_t *)ctx->k_map.p,
-                           (uint32_t *)ctx->block_state.p, chain_base, chain_len, (const uint32_t *)ctx->scalars.p, g);
+        StageTimer t(ctx, l, ST_RESOLVE);
+        launch_resolve<ET>(s, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
+                           (uint32_t *)l.block_state.p, chain_base, chain_len, (const uint32_t *)l.scalars.p, g);
     }
     {
-        StageTimer t(ctx, ST_LENGTHS);
-        launch_lengths<T>(s, d_planes, (const uint8_t *)ctx->k_map.p, (uint16_t *)ctx->group_bits.p,
-                          (uint32_t *)ctx->tile_bits.p, g);
+        StageTimer t(ctx, l, ST_LENGTHS);
+        launch_lengths<T>(s, d_planes, (const uint8_t *)l.k_map.p, (uint16_t *)l.group_bits.p, (uint32_t *)l.tile_bits.p, g);
     }
     {
-        StageTimer t(ctx, ST_BITSCAN);
-        launch_bitscan(s, (const uint32_t *)ctx->tile_bits.p, (uint64_t *)ctx->tile_bitoff.p,
-                       (uint64_t *)ctx->image_bytes.p, (uint64_t *)ctx->image_off.p, g);
+        StageTimer t(ctx, l, ST_BITSCAN);
+        launch_bitscan(s, (const uint32_t *)l.tile_bits.p, (uint64_t *)l.tile_bitoff.p, (uint64_t *)l.image_bytes.p,
+                       (uint64_t *)l.image_off.p, g);
     }
     HIP_TRY(ctx, hipGetLastError());
-    ctx->h_sizes.resize((size_t)g.nimages * 2 + 1);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_sizes.data(), ctx->image_bytes.p, (size_t)g.nimages * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_sizes.data() + g.nimages, ctx->image_off.p, (size_t)(g.nimages + 1) * 8,
-                                hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipMemcpyAsync(l.h_sizes, l.image_bytes.p, (size_t)g.nimages * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(l.h_sizes + g.nimages, l.image_off.p, (size_t)(g.nimages + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipEventRecord(l.sized, s));
     return FELICS_OK;
 }
 
 template <typename T>
-int emit(felics_ctx *ctx, const Geometry &g, const T *d_planes, uint8_t *d_out) {
-    hipStream_t s = ctx->stream;
+int emit(felics_ctx *ctx, Lane &l, uint8_t *d_out) {
+    const Geometry &g = l.g;
+    hipStream_t s = l.stream;
     {
-        StageTimer t(ctx, ST_ZERO);
-        launch_zero_streams(s, (uint32_t *)d_out, (const uint64_t *)ctx->image_off.p, g);
+        StageTimer t(ctx, l, ST_ZERO);
+        launch_zero_streams(s, (uint32_t *)d_out, (const uint64_t *)l.image_off.p, g);
     }
     {
-        StageTimer t(ctx, ST_PACK);
-        launch_pack<T>(s, d_planes, (const uint8_t *)ctx->k_map.p, (const uint16_t *)ctx->group_bits.p,
-                       (const uint64_t *)ctx->tile_bitoff.p, (const uint32_t *)ctx->tile_bits.p,
-                       (const uint64_t *)ctx->image_off.p, d_out, g);
+        StageTimer t(ctx, l, ST_PACK);
+        launch_pack<T>(s, (const T *)l.d_planes, (const uint8_t *)l.k_map.p, (const uint16_t *)l.group_bits.p,
+                       (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p,
+                       (const uint64_t *)l.image_off.p, d_out, g);
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(s));
     return FELICS_OK;
 }
 
 void collect_timing(felics_ctx *ctx) {
     if (!ctx->profiling) return;
     for (int i = 0; i < ST_COUNT; i++) {
-        ctx->stage_ms[i] = 0.f;
-        if (ctx->ev_used[i]) (void)hipEventElapsedTime(&ctx->stage_ms[i], ctx->ev[i][0], ctx->ev[i][1]);
+        ctx->stage_ms[i] = 0.f;  // sum over the lanes (lanes overlap: the sum can exceed wall time)
+        for (Lane &l : ctx->lanes) {
+            float ms = 0.f;
+            if (l.ev_used[i] && hipEventElapsedTime(&ms, l.ev[i][0], l.ev[i][1]) == hipSuccess) ctx->stage_ms[i] += ms;
+        }
     }
 }
 
-// images per sub-batch so that slots / chain bases stay below 2^32
+// images per pass so that slots / chain bases stay below 2^32
 size_t max_images_per_pass(uint64_t npix, uint32_t planes) {
     const uint64_t per_image = npix * planes;
     if (per_image == 0) return SIZE_MAX;
@@ -209,15 +241,17 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
     const uint64_t npix = (uint64_t)w * h;
     if (depth == FELICS_DEPTH_16) return FELICS_E_UNSUPPORTED;  // GPU path: 8-bit samples
     if (npix * planes >= 0xE0000000ull) return FELICS_E_UNSUPPORTED;
-    for (int i = 0; i < ST_COUNT; i++) ctx->ev_used[i] = false;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (Lane &l : ctx->lanes)
+        for (int i = 0; i < ST_COUNT; i++) l.ev_used[i] = false;
+    const bool own_out = d_out == nullptr;
 
     if (npix == 0) {
         // (0,_) | (_,0): header + two zero i32 per plane (compression.rs:94-98); nothing to compute
         const size_t sz = 14 + 8 * planes;
         const size_t stride = (sz + 15) & ~(size_t)15;
         const size_t need = stride * n;
-        if (!d_out) {
+        if (own_out) {
             int rc = reserve(ctx, ctx->out, need);
             if (rc) return rc;
             d_out = (uint8_t *)ctx->out.p;
@@ -238,55 +272,89 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
         return FELICS_OK;
     }
 
-    // Sub-batches keep every index below 2^32; streams of later sub-batches follow the earlier ones.
-    const size_t per_pass = max_images_per_pass(npix, planes);
     const size_t frame_bytes = (size_t)npix * planes;  // u8 samples
+    const size_t per_pass = max_images_per_pass(npix, planes);
     uint64_t out_base = 0;
-    const bool own_out = d_out == nullptr;
-    if (own_out && n > per_pass) return FELICS_E_UNSUPPORTED;  // host API splits before calling
-    for (size_t first = 0; first < n; first += per_pass) {
-        const size_t cnt = std::min(per_pass, n - first);
-        Geometry g;
-        g.W = w;
-        g.H = h;
-        g.npix = (uint32_t)npix;
-        g.nimages = (uint32_t)cnt;
-        g.planes_per_image = planes;
-        g.nplanes = (uint32_t)(cnt * planes);
-        g.sort_tiles = (uint32_t)((npix + SORT_TILE - 1) / SORT_TILE);
-        g.pack_tiles = (uint32_t)((npix + PACK_TILE - 1) / PACK_TILE);
-        g.color = (uint32_t)color;
-        g.depth = (uint32_t)depth;
-        const uint8_t *src = (const uint8_t *)d_pixels + first * frame_bytes;
-        int rc;
-        const void *d_planes = src;
-        if (planes == 3) {
-            if ((rc = reserve(ctx, ctx->planes, (size_t)g.nplanes * npix * 2)) != 0) return rc;
-            StageTimer t(ctx, ST_PLANES);
-            launch_rgb8_to_planes(ctx->stream, src, (int16_t *)ctx->planes.p, g.npix, g.nimages);
-            d_planes = ctx->planes.p;
+    size_t done = 0;
+    int rc;
+    // Rounds of up to MAX_LANES sub-batches: analyse all of them (their spines overlap the other
+    // lanes' data-parallel kernels), then place and pack the streams in image order.
+    while (done < n) {
+        const size_t left = n - done;
+        size_t nl = std::min<size_t>(MAX_LANES, std::max<size_t>(1, left / MIN_LANE_IMAGES));
+        size_t per_lane = std::min(per_pass, (left + nl - 1) / nl);
+        size_t first = done;
+        int used = 0;
+        for (size_t li = 0; li < nl && first < n; li++) {
+            Lane &l = ctx->lanes[li];
+            const size_t cnt = std::min(per_lane, n - first);
+            Geometry &g = l.g;
+            g.W = w;
+            g.H = h;
+            g.npix = (uint32_t)npix;
+            g.nimages = (uint32_t)cnt;
+            g.planes_per_image = planes;
+            g.nplanes = (uint32_t)(cnt * planes);
+            g.sort_tiles = (uint32_t)((npix + SORT_TILE - 1) / SORT_TILE);
+            g.pack_tiles = (uint32_t)((npix + PACK_TILE - 1) / PACK_TILE);
+            g.color = (uint32_t)color;
+            g.depth = (uint32_t)depth;
+            l.first_image = first;
+            const uint8_t *src = (const uint8_t *)d_pixels + first * frame_bytes;
+            l.d_planes = src;
+            if (planes == 3) {
+                if ((rc = reserve(ctx, l.planes, (size_t)g.nplanes * npix * 2 + STAGE_PAD)) != 0) return rc;
+                StageTimer t(ctx, l, ST_PLANES);
+                launch_rgb8_to_planes(l.stream, src, (int16_t *)l.planes.p, g.npix, g.nimages);
+                l.d_planes = l.planes.p;
+            }
+            rc = planes == 3 ? analyse<int16_t, uint16_t>(ctx, l) : analyse<uint8_t, uint8_t>(ctx, l);
+            if (rc) {
+                (void)sync_all(ctx);
+                return rc;
+            }
+            first += cnt;
+            used++;
         }
-        rc = planes == 3 ? analyse<int16_t, uint16_t>(ctx, g, (const int16_t *)d_planes)
-                         : analyse<uint8_t, uint8_t>(ctx, g, (const uint8_t *)d_planes);
-        if (rc) return rc;
-        const uint64_t need = ctx->h_sizes[(size_t)cnt * 2];  // image_off[cnt]
-        if (own_out) {
-            if ((rc = reserve(ctx, ctx->out, need)) != 0) return rc;
+        // sizes of this round
+        uint64_t round_need = 0;
+        if (own_out) {  // the context's buffer may have to grow: wait for every size first
+            for (int li = 0; li < used; li++) {
+                HIP_TRY(ctx, hipEventSynchronize(ctx->lanes[li].sized));
+                round_need += ctx->lanes[li].h_sizes[(size_t)ctx->lanes[li].g.nimages * 2];
+            }
+            if (out_base != 0) return FELICS_E_UNSUPPORTED;  // host entry points submit one round at a time
+            if ((rc = reserve(ctx, ctx->out, round_need)) != 0) return rc;
             d_out = (uint8_t *)ctx->out.p;
             d_out_cap = ctx->out.cap;
         }
-        if (out_base + need > d_out_cap) {
-            lens[0] = out_base + need;  // lower bound when more sub-batches follow
+        bool too_small = false;
+        for (int li = 0; li < used; li++) {
+            Lane &l = ctx->lanes[li];
+            HIP_TRY(ctx, hipEventSynchronize(l.sized));
+            const size_t cnt = l.g.nimages;
+            const uint64_t need = l.h_sizes[cnt * 2];  // image_off[cnt]
+            if (!too_small && out_base + need <= d_out_cap) {
+                rc = planes == 3 ? emit<int16_t>(ctx, l, d_out + out_base) : emit<uint8_t>(ctx, l, d_out + out_base);
+                if (rc) {
+                    (void)sync_all(ctx);
+                    return rc;
+                }
+            } else {
+                too_small = true;
+            }
+            for (size_t i = 0; i < cnt; i++) {
+                lens[l.first_image + i] = l.h_sizes[i];
+                offsets[l.first_image + i] = out_base + l.h_sizes[cnt + i];
+            }
+            out_base += need;
+        }
+        if ((rc = sync_all(ctx)) != 0) return rc;
+        if (too_small) {
+            lens[0] = out_base;  // capacity needed so far (a lower bound if more rounds would follow)
             return FELICS_E_BUFFER_TOO_SMALL;
         }
-        rc = planes == 3 ? emit<int16_t>(ctx, g, (const int16_t *)d_planes, d_out + out_base)
-                         : emit<uint8_t>(ctx, g, (const uint8_t *)d_planes, d_out + out_base);
-        if (rc) return rc;
-        for (size_t i = 0; i < cnt; i++) {
-            lens[first + i] = ctx->h_sizes[i];
-            offsets[first + i] = out_base + ctx->h_sizes[cnt + i];
-        }
-        out_base += need;
+        done = first;
     }
     collect_timing(ctx);
     if (used_out) *used_out = d_out;
@@ -310,16 +378,17 @@ int felics_ctx_create(int device, felics_ctx **out) {
     felics_ctx *ctx = new (std::nothrow) felics_ctx();
     if (!ctx) return FELICS_E_IO;
     ctx->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete ctx;
+    bool ok = hipSetDevice(device) == hipSuccess;
+    for (Lane &l : ctx->lanes) {
+        ok = ok && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&l.sized, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < ST_COUNT && ok; i++)
+            for (int j = 0; j < 2 && ok; j++) ok = hipEventCreate(&l.ev[i][j]) == hipSuccess;
+    }
+    if (!ok) {
+        felics_ctx_destroy(ctx);
         return FELICS_E_HIP;
     }
-    for (int i = 0; i < ST_COUNT; i++)
-        for (int j = 0; j < 2; j++)
-            if (hipEventCreate(&ctx->ev[i][j]) != hipSuccess) {
-                felics_ctx_destroy(ctx);
-                return FELICS_E_HIP;
-            }
     *out = ctx;
     return FELICS_OK;
 }
@@ -327,15 +396,20 @@ int felics_ctx_create(int device, felics_ctx **out) {
 void felics_ctx_destroy(felics_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->in, &ctx->planes, &ctx->counts, &ctx->chain_len, &ctx->chain_base, &ctx->scalars,
-                      &ctx->sorted_e, &ctx->pix_of, &ctx->k_map, &ctx->block_state, &ctx->group_bits, &ctx->tile_bits, &ctx->tile_bitoff,
-                      &ctx->image_bytes, &ctx->image_off, &ctx->out};
-    for (DevBuf *b : bufs) release(*b);
-    for (int i = 0; i < ST_COUNT; i++)
-        for (int j = 0; j < 2; j++)
-            if (ctx->ev[i][j]) (void)hipEventDestroy(ctx->ev[i][j]);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (Lane &l : ctx->lanes) {
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
+        DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map,
+                          &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.image_bytes, &l.image_off};
+        for (DevBuf *b : bufs) release(*b);
+        if (l.h_sizes) (void)hipHostFree(l.h_sizes);
+        for (int i = 0; i < ST_COUNT; i++)
+            for (int j = 0; j < 2; j++)
+                if (l.ev[i][j]) (void)hipEventDestroy(l.ev[i][j]);
+        if (l.sized) (void)hipEventDestroy(l.sized);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
+    release(ctx->in);
+    release(ctx->out);
     delete ctx;
 }
 
@@ -375,8 +449,9 @@ int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, 
         for (size_t i = 0; i < cnt && frame_bytes; i++) {
             if (!pixels[first + i]) return FELICS_E_INVALID_ARGUMENT;
             HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)ctx->in.p + i * frame_bytes, pixels[first + i], frame_bytes,
-                                        hipMemcpyHostToDevice, ctx->stream));
+                                        hipMemcpyHostToDevice, ctx->lanes[0].stream));
         }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->lanes[0].stream));  // the other lanes read ctx->in too
         offs.assign(cnt, 0);
         sizes.assign(cnt, 0);
         uint8_t *d_out = nullptr;
@@ -389,9 +464,9 @@ int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, 
                 continue;
             }
             HIP_TRY(ctx, hipMemcpyAsync(outs[first + i], d_out + offs[i], (size_t)sizes[i], hipMemcpyDeviceToHost,
-                                        ctx->stream));
+                                        ctx->lanes[0].stream));
         }
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->lanes[0].stream));
     }
     return result;
 }

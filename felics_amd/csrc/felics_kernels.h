@@ -17,8 +17,8 @@ constexpr uint32_t SORT_TILE = 16384;
 constexpr uint32_t PACK_THREADS = 256;
 constexpr uint32_t PACK_PER_THREAD = 16;
 constexpr uint32_t PACK_TILE = PACK_THREADS * PACK_PER_THREAD;
-// LDS bit window of the pack stage: 4096 words = 16 KiB = 32 bits per pixel of a tile
-constexpr uint32_t PACK_WIN_WORDS = 4096;
+// LDS bit window of the pack stage: 2048 words = 8 KiB = 16 bits per pixel of a tile (more bits: more windows)
+constexpr uint32_t PACK_WIN_WORDS = 2048;
 
 struct Geometry {
     uint32_t W, H;

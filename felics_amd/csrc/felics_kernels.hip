@@ -49,6 +49,11 @@ __device__ __forceinline__ uint32_t readlane(uint32_t v, uint32_t l) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
 }
 
+// number of set bits of m below this lane
+__device__ __forceinline__ uint32_t mbcnt(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // ------------------------------------------------------------------------------------------
 // per-pixel classification shared by hist / scatter / lengths / pack
 // ------------------------------------------------------------------------------------------
@@ -261,7 +266,6 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
     const uint32_t plane_first = plane * npix;
     const uint32_t begin = tile * SORT_TILE;
     const uint32_t end = min(begin + SORT_TILE, npix);
-    const uint64_t lt = lanemask_lt();
     Coord xy;
     xy.set(begin + lane, W);
     for (uint32_t row = begin; row < end; row += 64) {
@@ -275,20 +279,40 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
             e = pc.val;
         }
         xy.advance(64, W);
-        uint64_t pending = __ballot(ev);
-        uint32_t dest = 0;
+        // Rank the lanes that share a context with ballots only (no memory in the loop): every event
+        // lane learns how many earlier lanes of this row hold its context (rank) and how many lanes
+        // hold it in all (group).  Contexts 0..HOT-1 carry most events of real images: they are ranked
+        // by HOT independent ballots; whatever is left goes through the one-context-per-trip loop.
+        uint32_t rank = 0, group = 0;
+        constexpr uint32_t HOT = 8;
+#pragma unroll
+        for (uint32_t t = 0; t < HOT; t++) {
+            const bool mine = ev && c == t;
+            const uint64_t m = __ballot(mine);
+            if (mine) {
+                rank = mbcnt(m);
+                group = (uint32_t)__popcll(m);
+            }
+        }
+        uint64_t pending = __ballot(ev && c >= HOT);
         while (pending) {
             const uint32_t src = (uint32_t)__ffsll((long long)pending) - 1u;
             const uint32_t cc = readlane(c, src);
             const bool mine = ev && c == cc;
             const uint64_t m = __ballot(mine);
-            const uint32_t basev = run[cc];
-            if (mine) dest = basev + (uint32_t)__popcll(m & lt);
-            __builtin_amdgcn_wave_barrier();
-            if (lane == src) run[cc] = basev + (uint32_t)__popcll(m);
-            __builtin_amdgcn_wave_barrier();
+            if (mine) {
+                rank = mbcnt(m);
+                group = (uint32_t)__popcll(m);
+            }
             pending &= ~m;
         }
+        const bool leader = ev && rank == 0;  // first lane of its context in this row
+        // one LDS read per lane (same context -> same address -> broadcast), one write per leader
+        uint32_t dest = 0;
+        if (ev) dest = run[c] + rank;
+        __builtin_amdgcn_wave_barrier();
+        if (leader) run[c] = dest + group;  // the leader has rank 0: dest is the context's running offset
+        __builtin_amdgcn_wave_barrier();
         if (ev) {
             sorted_e[dest] = (ET)e;
             pix_of[dest] = plane_first + i;
@@ -359,6 +383,7 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
     if (n == 0) return;
     const uint32_t lane = lane_id();
     const uint32_t l7 = lane & 7u;
+    __builtin_amdgcn_s_setprio(3);  // a chain is one long dependent instruction stream: never make it wait for issue
     const uint32_t base = chain_base[chain];  // multiple of 64
     const uint32_t nblocks = (n + 63u) >> 6;
     const uint4 *src = reinterpret_cast<const uint4 *>(sorted_e + base);  // block b = DW/4 uint4 at b*DW/4
@@ -580,11 +605,14 @@ __device__ __forceinline__ int sample_at(const uint32_t *w, uint32_t j, int16_t)
     return (int)(int16_t)(w[j >> 1] >> (16u * (j & 1u)));
 }
 
-// Calls f(i, raw, raw_value, pc, k) for every pixel i of this thread's group, in raster order.
-// raw == true for pixels 0 and 1 of the plane (stored as 32-bit values, compression.rs:105-106).
-template <typename T, typename F>
+// Calls raw(i, value) for pixels 0 and 1 of the plane (stored as 32-bit values,
+// compression.rs:105-106) and f(pc, k) for every other pixel of this thread's group, in raster order.
+// The neighbour rule (misc.rs:6-24) is applied from registers: the left neighbours come from the
+// group itself, the row above from `up`; only the second neighbour of a first-column pixel
+// (two rows up) is fetched from global memory, once per image row.
+template <typename T, typename FR, typename F>
 __device__ __forceinline__ void walk_group(const TileLDS<T> &t, const T *__restrict__ pl, uint32_t first, uint32_t end,
-                                           uint32_t W, F &&f) {
+                                           uint32_t W, FR &&raw, F &&f) {
     if (first >= end) return;
     constexpr uint32_t NW = PACK_PER_THREAD * sizeof(T) / 4;  // dwords holding the group's pixels
     const uint32_t off = threadIdx.x * PACK_PER_THREAD;
@@ -600,34 +628,59 @@ __device__ __forceinline__ void walk_group(const TileLDS<T> &t, const T *__restr
         const uint4 c = *reinterpret_cast<const uint4 *>(t.kq + off);
         kw[0] = c.x; kw[1] = c.y; kw[2] = c.z; kw[3] = c.w;
     }
-    int left = (int)t.cur[STAGE_LEAD + off - 1];
+    int left = (int)t.cur[STAGE_LEAD + off - 1], left2 = (int)t.cur[STAGE_LEAD + off - 2];
+    for (uint32_t i = first; i < min(end, 2u); i++) raw(i, (uint32_t)(int)pl[i]);
     Coord xy;
     xy.set(first, W);
+    // Four pixels per trip; the register arrays are shifted down after each trip so that every
+    // index below is a compile-time constant while the loop itself stays rolled (code size).
+    constexpr uint32_t D = sizeof(T);  // dwords per four pixels
+    uint32_t up_tail = (uint32_t)(int)t.up[off + PACK_PER_THREAD];  // above-right of the group's last pixel
+#pragma nounroll
+    for (uint32_t g = 0; g < PACK_PER_THREAD; g += 4) {
+        const uint32_t un = NW > D ? uw[NW > D ? D : 0] : up_tail;  // dword after this trip's `up` samples
 #pragma unroll
-    for (uint32_t j = 0; j < PACK_PER_THREAD; j++) {
-        const uint32_t i = first + j;
-        const int p = sample_at(cw, j, T());
-        if (i < end) {
-            const uint32_t k = (kw[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
-            if (i < 2) {
-                f(i, true, (uint32_t)p, PixelClass{0, 0, 0}, 0u);
-            } else if (xy.x > 0 && xy.y > 0) {
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t i = first + g + j;
+            const int p = sample_at(cw, j, T());
+            if (i < end && i >= 2) {
+                const uint32_t k = (kw[0] >> (8u * j)) & 0xFFu;
                 const int above = sample_at(uw, j, T());
-                const int H = max(left, above), L = min(left, above);
+                int v1 = left, v2 = above;  // interior: left and above
+                if (xy.y == 0) {
+                    v2 = left2;  // first row: the two pixels to the left
+                } else if (xy.x == 0) {
+                    v1 = above;  // first column: above and ...
+                    if (xy.y >= 2)
+                        v2 = (int)pl[i - 2 * W];  // ... two rows up,
+                    else                          // or above-right for pixel (0,1)
+                        v2 = j < 3 ? sample_at(uw, (j + 1) & 3u, T()) : sample_at(&un, 0, T());
+                }
+                const int H = max(v1, v2), L = min(v1, v2);
                 PixelClass pc;
                 pc.ctx = (uint32_t)(H - L);
                 pc.cls = p < L ? CLS_BELOW : (p > H ? CLS_ABOVE : CLS_IN);
                 pc.val = p < L ? (uint32_t)(L - p - 1) : (p > H ? (uint32_t)(p - H - 1) : (uint32_t)(p - L));
-                f(i, false, 0u, pc, k);
-            } else {
-                f(i, false, 0u, classify(pl, i, xy.x, xy.y, W), k);
+                f(pc, k);
+            }
+            left2 = left;
+            left = p;
+            if (++xy.x == W) {
+                xy.x = 0;
+                xy.y++;
             }
         }
-        left = p;
-        if (++xy.x == W) {
-            xy.x = 0;
-            xy.y++;
+#pragma unroll
+        for (uint32_t q = 0; q + D < NW; q++) {
+            cw[q] = cw[q + D];
+            uw[q] = uw[q + D];
         }
+        // once the real samples are used up, the next dword of `up` is the tail element
+#pragma unroll
+        for (uint32_t q = NW - D; q < NW; q++) uw[q] = up_tail;
+        kw[0] = kw[1];
+        kw[1] = kw[2];
+        kw[2] = kw[3];
     }
 }
 
@@ -651,9 +704,8 @@ __global__ __launch_bounds__(PACK_THREADS) void k_lengths(const T *__restrict__ 
     const uint32_t first = tile_first + threadIdx.x * PACK_PER_THREAD;
     const uint32_t end = min(tile_first + PACK_TILE, npix);
     uint32_t bits = 0;
-    walk_group(tl, pl, first, end, W, [&](uint32_t, bool raw, uint32_t, const PixelClass &pc, uint32_t k) {
-        bits += raw ? 32u : code_length(pc, k);
-    });
+    walk_group(tl, pl, first, end, W, [&](uint32_t, uint32_t) { bits += 32u; },
+               [&](const PixelClass &pc, uint32_t k) { bits += code_length(pc, k); });
     if (npix == 1 && first == 0) bits += 32;  // 1x1: second raw value is a literal 0 (compression.rs:99-103)
     if (tile == 0 && threadIdx.x == 0 && (plane % planes_per_image) == 0) bits += 8 * 14;  // header
     group_bits[((uint64_t)plane * ntiles + tile) * PACK_THREADS + threadIdx.x] = (uint16_t)bits;
@@ -845,14 +897,12 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ pla
                 bw.put(W, 32);
                 bw.put(H, 32);
             }
-            walk_group(tl, pl, first, end, W, [&](uint32_t, bool raw, uint32_t rv, const PixelClass &pc, uint32_t k) {
-                if (raw) {
-                    bw.put(rv, 32);  // write_signed(32, p): sign-extended sample
-                    if (npix == 1) bw.put(0u, 32);
-                } else {
-                    put_pixel(bw, pc, k);
-                }
-            });
+            walk_group(tl, pl, first, end, W,
+                       [&](uint32_t, uint32_t rv) {
+                           bw.put(rv, 32);  // write_signed(32, p): sign-extended sample
+                           if (npix == 1) bw.put(0u, 32);
+                       },
+                       [&](const PixelClass &pc, uint32_t k) { put_pixel(bw, pc, k); });
             bw.finish();
         }
         __syncthreads();

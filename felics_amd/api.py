@@ -78,7 +78,7 @@ EXPORTS = [
     "felics_ctx_create", "felics_ctx_destroy", "felics_max_compressed_size", "felics_compress",
     "felics_compress_batch", "felics_compress_batch_device", "felics_read_header", "felics_write_header",
     "felics_decompress", "felics_strerror", "felics_last_error", "felics_set_profiling",
-    "felics_stage_count", "felics_stage_name", "felics_get_stage_ms",
+    "felics_stage_count", "felics_stage_name", "felics_get_stage_ms", "felics_lane_count",
 ]
 
 _lib = None

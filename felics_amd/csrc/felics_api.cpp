@@ -16,8 +16,8 @@ using namespace felics;
 
 namespace {
 
-enum Stage { ST_PLANES = 0, ST_HIST, ST_OFFSETS, ST_SCATTER, ST_RESOLVE, ST_LENGTHS, ST_BITSCAN, ST_ZERO, ST_PACK, ST_COUNT };
-const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "resolve", "lengths", "bitscan", "zero", "pack"};
+enum Stage { ST_PLANES = 0, ST_HIST, ST_OFFSETS, ST_SCATTER, ST_SPINE, ST_ASSIGN, ST_LENGTHS, ST_BITSCAN, ST_ZERO, ST_PACK, ST_COUNT };
+const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "spine", "assign", "lengths", "bitscan", "zero", "pack"};
 
 constexpr int MAX_LANES = 3;            // sub-batches in flight, one HIP stream each (ROCm maps streams onto 4 hardware queues; the caller usually owns one)
 constexpr size_t MIN_LANE_IMAGES = 8;   // below this a sub-batch does not fill the GPU
@@ -177,9 +177,14 @@ int analyse(felics_ctx *ctx, Lane &l) {
         launch_scatter<T, ET>(s, d_planes, counts, chain_base, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, g);
     }
     {
-        StageTimer t(ctx, l, ST_RESOLVE);
-        launch_resolve<ET>(s, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
-                           (uint32_t *)l.block_state.p, chain_base, chain_len, (const uint32_t *)l.scalars.p, g);
+        StageTimer t(ctx, l, ST_SPINE);
+        launch_spine<ET>(s, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, (uint32_t *)l.block_state.p, chain_base,
+                         chain_len, g);
+    }
+    {
+        StageTimer t(ctx, l, ST_ASSIGN);
+        launch_assign<ET>(s, (const ET *)l.sorted_e.p, (const uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
+                          (const uint32_t *)l.block_state.p, (const uint32_t *)l.scalars.p, g);
     }
     {
         StageTimer t(ctx, l, ST_LENGTHS);
@@ -522,6 +527,8 @@ int felics_set_profiling(felics_ctx *ctx, int enabled) {
 }
 
 int felics_stage_count(void) { return ST_COUNT; }
+
+int felics_lane_count(void) { return MAX_LANES; }
 
 const char *felics_stage_name(int stage) { return stage >= 0 && stage < ST_COUNT ? kStageNames[stage] : ""; }
 

@@ -54,10 +54,14 @@ constexpr size_t SORTED_PAD = 64 * 64 * 2 + 256;
 // k_map / plane buffers are read in whole 16-byte chunks by the tile staging
 constexpr size_t STAGE_PAD = 64;
 
+// resolve = spine (sequential per chain: state at every 64-event block) + assign (k of every event)
 template <typename ET>
-void launch_resolve(hipStream_t s, ET *sorted_e, uint32_t *pix_of, uint8_t *k_map, uint32_t *block_state,
-                    const uint32_t *chain_base, const uint32_t *chain_len, const uint32_t *total_slots,
-                    const Geometry &g);
+void launch_spine(hipStream_t s, ET *sorted_e, uint32_t *pix_of, uint32_t *block_state, const uint32_t *chain_base,
+                  const uint32_t *chain_len, const Geometry &g);
+
+template <typename ET>
+void launch_assign(hipStream_t s, const ET *sorted_e, const uint32_t *pix_of, uint8_t *k_map,
+                   const uint32_t *block_state, const uint32_t *total_slots, const Geometry &g);
 
 template <typename T>
 void launch_lengths(hipStream_t s, const T *planes, const uint8_t *k_map, uint16_t *group_bits, uint32_t *tile_bits,

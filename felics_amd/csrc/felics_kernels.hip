@@ -961,22 +961,30 @@ template void launch_scatter<int16_t, uint16_t>(hipStream_t, const int16_t *, co
                                                 uint16_t *, uint32_t *, const Geometry &);
 
 template <typename ET>
-void launch_resolve(hipStream_t s, ET *sorted_e, uint32_t *pix_of, uint8_t *k_map, uint32_t *block_state,
-                    const uint32_t *chain_base, const uint32_t *chain_len, const uint32_t *total_slots,
-                    const Geometry &g) {
+void launch_spine(hipStream_t s, ET *sorted_e, uint32_t *pix_of, uint32_t *block_state, const uint32_t *chain_base,
+                  const uint32_t *chain_len, const Geometry &g) {
     const uint32_t nchains = g.nplanes * NCTX;
     hipLaunchKernelGGL((k_zero_padding<ET>), dim3(cdiv(nchains, 256)), dim3(256), 0, s, sorted_e, pix_of, chain_base,
                        chain_len, nchains);
     hipLaunchKernelGGL((k_spine<ET>), dim3(nchains), dim3(64), 0, s, (const ET *)sorted_e, block_state, chain_base,
                        chain_len, nchains);
-    const uint32_t max_blocks = max_event_blocks(g);
-    hipLaunchKernelGGL((k_assign<ET>), dim3(cdiv(max_blocks, 4)), dim3(256), 0, s, (const ET *)sorted_e,
-                       (const uint32_t *)block_state, (const uint32_t *)pix_of, k_map, total_slots);
 }
-template void launch_resolve<uint8_t>(hipStream_t, uint8_t *, uint32_t *, uint8_t *, uint32_t *, const uint32_t *,
-                                      const uint32_t *, const uint32_t *, const Geometry &);
-template void launch_resolve<uint16_t>(hipStream_t, uint16_t *, uint32_t *, uint8_t *, uint32_t *, const uint32_t *,
-                                       const uint32_t *, const uint32_t *, const Geometry &);
+template void launch_spine<uint8_t>(hipStream_t, uint8_t *, uint32_t *, uint32_t *, const uint32_t *,
+                                    const uint32_t *, const Geometry &);
+template void launch_spine<uint16_t>(hipStream_t, uint16_t *, uint32_t *, uint32_t *, const uint32_t *,
+                                     const uint32_t *, const Geometry &);
+
+template <typename ET>
+void launch_assign(hipStream_t s, const ET *sorted_e, const uint32_t *pix_of, uint8_t *k_map,
+                   const uint32_t *block_state, const uint32_t *total_slots, const Geometry &g) {
+    const uint32_t max_blocks = max_event_blocks(g);
+    hipLaunchKernelGGL((k_assign<ET>), dim3(cdiv(max_blocks, 4)), dim3(256), 0, s, sorted_e, block_state, pix_of, k_map,
+                       total_slots);
+}
+template void launch_assign<uint8_t>(hipStream_t, const uint8_t *, const uint32_t *, uint8_t *, const uint32_t *,
+                                     const uint32_t *, const Geometry &);
+template void launch_assign<uint16_t>(hipStream_t, const uint16_t *, const uint32_t *, uint8_t *, const uint32_t *,
+                                      const uint32_t *, const Geometry &);
 
 template <typename T>
 void launch_lengths(hipStream_t s, const T *planes, const uint8_t *k_map, uint16_t *group_bits, uint32_t *tile_bits,

@@ -14,7 +14,7 @@
  *     interleaved RGBRGB... when color == FELICS_COLOR_RGB -- the layout of
  *     `ImageBuffer::as_raw()` (compression.rs:276, :338);
  *   - the caller owns every buffer; the library keeps no pointer after return;
- *   - a context is bound to one GPU and one HIP stream and is not thread-safe:
+ *   - a context is bound to one GPU (it owns a few HIP streams) and is not thread-safe:
  *     use one context per host thread / per GPU (the reference is single
  *     threaded and re-entrant on distinct images);
  *   - ENCODE RUNS ON THE GPU ONLY.  There is no CPU encode fallback: without a
@@ -125,6 +125,9 @@ int felics_set_profiling(felics_ctx *ctx, int enabled);
 int felics_stage_count(void);
 const char *felics_stage_name(int stage);
 int felics_get_stage_ms(const felics_ctx *ctx, float *ms, int cap);
+/* A submission is split into up to this many sub-batches, each on its own HIP stream; a stage's
+ * milliseconds are summed over them (they overlap, so the sum can exceed wall time). */
+int felics_lane_count(void);
 
 #ifdef __cplusplus
 }

@@ -166,3 +166,48 @@ def test_suite_images(enc, oracle):
 
     for p in sorted(glob.glob("/root/reference/image-suite/grayscale/8bit/*"))[:10]:
         _check(enc, oracle, np.array(Image.open(p)), p)
+
+
+def test_cfelics_dfelics_cli(tmp_path):
+    """src/bin/cfelics.rs / dfelics.rs as a user runs them: TIFF -> .felics (GPU) -> TIFF."""
+    import subprocess
+
+    from PIL import Image
+
+    build = os.path.join(os.path.dirname(os.path.dirname(__file__)), "felics_amd", "_build")
+    for name, line in (("6.3.09.tiff", "Compressing 8-bit grayscale image..."), ("house.tiff", "Compressing 8-bit rgb image..."),
+                       ("lena_color_256.tif", "Compressing 8-bit rgb image...")):
+        out = str(tmp_path / (name + ".felics"))
+        r = subprocess.run([os.path.join(build, "cfelics"), "-i", os.path.join(GOLDEN, name), "-o", out],
+                           capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.strip() == line, r.stdout + r.stderr
+        assert open(out, "rb").read() == open(os.path.join(GOLDEN, name + ".felics"), "rb").read()
+        back = str(tmp_path / (name + ".back.tiff"))
+        r = subprocess.run([os.path.join(build, "dfelics"), "-i", out, "-o", back], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert (np.array(Image.open(back)) == np.array(Image.open(os.path.join(GOLDEN, name)))).all()
+    r = subprocess.run([os.path.join(build, "cfelics"), "-i", os.path.join(GOLDEN, "aerial.tiff"), "-o", str(tmp_path / "a.felics")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and r.stdout.splitlines()[0] == "Compressing 16-bit grayscale image..."
+    assert r.stdout.splitlines()[1].startswith("Cannot compress image:")
+
+
+def test_odd_geometry(enc, oracle):
+    """Widths that are not multiples of 16 (unaligned rows in the tile staging), tiles that end mid-row,
+    very narrow and very wide images."""
+    rng = np.random.default_rng(31)
+    for w, h in ((17, 300), (4097, 3), (4095, 5), (3, 3000), (2, 5000), (1, 5000), (5000, 1), (5000, 2), (255, 257), (1023, 65)):
+        _check(enc, oracle, rng.integers(0, 256, size=(h, w), dtype=np.uint8), "odd gray")
+        smooth = (np.add.outer(np.arange(h), np.arange(w)) // 3 % 256).astype(np.uint8)
+        _check(enc, oracle, smooth, "odd smooth")
+        _check(enc, oracle, rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8), "odd rgb")
+
+
+def test_batch_sizes_and_lanes(enc, oracle):
+    """Batches below, at and above the sub-batch pipeline's thresholds give the same streams."""
+    from felics_amd import synth
+
+    frames = [synth.gray8(200, 100, f, "S1" if f % 3 else "S2") for f in range(37)]
+    want = [oracle.compress(f) for f in frames]
+    for n in (1, 7, 8, 16, 25, 37):
+        assert enc.compress_batch(frames[:n]) == want[:n], n

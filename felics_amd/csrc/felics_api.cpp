@@ -286,13 +286,16 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
     // lanes' data-parallel kernels), then place and pack the streams in image order.
     while (done < n) {
         const size_t left = n - done;
-        size_t nl = std::min<size_t>(MAX_LANES, std::max<size_t>(1, left / MIN_LANE_IMAGES));
-        size_t per_lane = std::min(per_pass, (left + nl - 1) / nl);
+        const size_t nl = std::min<size_t>(MAX_LANES, std::max<size_t>(1, left / MIN_LANE_IMAGES));
+        // Later lanes get fewer images (weights nl, nl-1, .., 1): every lane pays the same spine
+        // latency, so the lane that starts last should have the least work left after its spine.
+        const size_t wsum = nl * (nl + 1) / 2;
         size_t first = done;
         int used = 0;
         for (size_t li = 0; li < nl && first < n; li++) {
             Lane &l = ctx->lanes[li];
-            const size_t cnt = std::min(per_lane, n - first);
+            size_t share = li + 1 == nl ? n - first : (left * (nl - li) + wsum - 1) / wsum;
+            const size_t cnt = std::min(std::min(per_pass, std::max<size_t>(1, share)), n - first);
             Geometry &g = l.g;
             g.W = w;
             g.H = h;

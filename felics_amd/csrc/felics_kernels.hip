@@ -187,7 +187,18 @@ __global__ void k_tile_offsets(uint32_t *__restrict__ counts, uint32_t *__restri
     uint32_t plane = g / NCTX, c = g - plane * NCTX;
     uint32_t *col = counts + (uint64_t)plane * ntiles * NCTX + c;
     uint32_t run = 0;
-    for (uint32_t t = 0; t < ntiles; t++) {
+    uint32_t t = 0;
+    for (; t + 8 <= ntiles; t += 8) {  // eight independent loads in flight, then the running sum
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) v[u] = col[(uint64_t)(t + u) * NCTX];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) {
+            col[(uint64_t)(t + u) * NCTX] = run;
+            run += v[u];
+        }
+    }
+    for (; t < ntiles; t++) {
         uint32_t v = col[(uint64_t)t * NCTX];
         col[(uint64_t)t * NCTX] = run;
         run += v;
@@ -432,8 +443,6 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
                 continue;
             }
             // a halving happens inside this block: find it with the block's per-event prefix sums
-            uint32_t S0 = readlane(Sv, 0), S1 = readlane(Sv, 1), S2 = readlane(Sv, 2);
-            uint32_t S3 = readlane(Sv, 3), S4 = readlane(Sv, 4), S5 = readlane(Sv, 5);
             const uint32_t e = (uint32_t) reinterpret_cast<const ET *>(stage)[j * 64 + lane];
             uint32_t l01, l23, l45;
             packed_lengths(e, l01, l23, l45);
@@ -442,25 +451,26 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
             const uint32_t P4 = p45 & 0xFFFFu, P5 = p45 >> 16;
             uint32_t lo = 0;
             while (true) {
+                uint32_t S0 = readlane(Sv, 0), S1 = readlane(Sv, 1), S2 = readlane(Sv, 2);
+                uint32_t S3 = readlane(Sv, 3), S4 = readlane(Sv, 4), S5 = readlane(Sv, 5);
                 const uint32_t mn = min(min(min(S0 + P0, S1 + P1), min(S2 + P2, S3 + P3)), min(S4 + P4, S5 + P5));
                 const uint64_t hm = __ballot(lane >= lo && mn > 1024u);
-                if (hm == 0) break;
+                // (the block-level test said a halving exists, and after a halving the loop is only
+                // re-entered when the end state says there is another: hm is never empty here)
                 const uint32_t f = (uint32_t)__ffsll((long long)hm) - 1u;
                 const uint32_t f0 = readlane(P0, f), f1 = readlane(P1, f), f2 = readlane(P2, f);
                 const uint32_t f3 = readlane(P3, f), f4 = readlane(P4, f), f5 = readlane(P5, f);
                 // S <- ((S + P(f)) >> 1) - P(f): later lanes add their own P(t) >= P(f) back (mod 2^32)
                 S0 = ((S0 + f0) >> 1) - f0; S1 = ((S1 + f1) >> 1) - f1; S2 = ((S2 + f2) >> 1) - f2;
                 S3 = ((S3 + f3) >> 1) - f3; S4 = ((S4 + f4) >> 1) - f4; S5 = ((S5 + f5) >> 1) - f5;
+                const uint32_t s01 = l7 == 0 ? S0 : S1, s23 = l7 == 2 ? S2 : S3, s45 = l7 == 4 ? S4 : S5;
+                Sv = l7 < 2 ? s01 : l7 < 4 ? s23 : l7 < 6 ? s45 : 0u;
                 lo = f + 1;
-                if (lo >= 64) break;
-                // state at the end of the block if nothing else happens; another round only if it would halve
-                const uint32_t E0 = S0 + readlane(Bv, 0), E1 = S1 + readlane(Bv, 1), E2 = S2 + readlane(Bv, 2);
-                const uint32_t E3 = S3 + readlane(Bv, 3), E4 = S4 + readlane(Bv, 4), E5 = S5 + readlane(Bv, 5);
-                if (min(min(min(E0, E1), min(E2, E3)), min(E4, E5)) <= 1024u) break;
+                // state at the end of the block if nothing else happens (block sums = prefix sums at
+                // lane 63); another round only if that still has all six counters above 1024
+                if (lo >= 64 || ((uint32_t)__ballot(Sv + Bv > 1024u) & 0x3Fu) != 0x3Fu) break;
             }
-            // block sums are the prefix sums at lane 63
-            const uint32_t s01 = l7 == 0 ? S0 : S1, s23 = l7 == 2 ? S2 : S3, s45 = l7 == 4 ? S4 : S5;
-            Sv = (l7 < 2 ? s01 : l7 < 4 ? s23 : l7 < 6 ? s45 : 0u) + Bv;
+            Sv += Bv;
             Bv = Bnext;
         }
         __syncthreads();
@@ -481,43 +491,64 @@ __global__ __launch_bounds__(256) void k_assign(const ET *__restrict__ sorted_e,
                                                 const uint32_t *__restrict__ total_slots) {
     const uint32_t lane = lane_id();
     const uint32_t nblocks = *total_slots >> 6;
-    const uint32_t gb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const uint32_t nwaves = gridDim.x * 4;
+    uint32_t gb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (gb >= nblocks) return;
-    const uint4 *st = reinterpret_cast<const uint4 *>(block_state) + (uint64_t)gb * 2;
-    const uint4 sa = st[0], sb = st[1];
-    uint32_t S0 = sa.x, S1 = sa.y, S2 = sa.z, S3 = sa.w, S4 = sb.x, S5 = sb.y;
-    const uint32_t e = (uint32_t)sorted_e[(uint64_t)gb * 64 + lane];
-    uint32_t l01, l23, l45;
-    packed_lengths(e, l01, l23, l45);
-    const uint32_t p01 = wave_incl_scan(l01), p23 = wave_incl_scan(l23), p45 = wave_incl_scan(l45);
-    const uint32_t P0 = p01 & 0xFFFFu, P1 = p01 >> 16, P2 = p23 & 0xFFFFu, P3 = p23 >> 16;
-    const uint32_t P4 = p45 & 0xFFFFu, P5 = p45 >> 16;
-    const uint32_t l0 = l01 & 0xFFFFu, l1 = l01 >> 16, l2 = l23 & 0xFFFFu, l3 = l23 >> 16, l4 = l45 & 0xFFFFu, l5 = l45 >> 16;
-    uint32_t kk = 0, lo = 0;
+    // grid-stride over the blocks; the next block's inputs are requested before this one is resolved
+    const uint4 *st = reinterpret_cast<const uint4 *>(block_state);
+    uint4 sa = st[(uint64_t)gb * 2], sb = st[(uint64_t)gb * 2 + 1];
+    uint32_t e = (uint32_t)sorted_e[(uint64_t)gb * 64 + lane];
+    uint32_t pix = pix_of[(uint64_t)gb * 64 + lane];
     while (true) {
-        const uint32_t T0 = S0 + P0, T1 = S1 + P1, T2 = S2 + P2, T3 = S3 + P3, T4 = S4 + P4, T5 = S5 + P5;
-        const uint32_t mn = min(min(min(T0, T1), min(T2, T3)), min(T4, T5));
-        // state BEFORE this lane's event -> its k (get_k precedes update, compression.rs:127,139)
-        const uint32_t X0 = T0 - l0, X1 = T1 - l1, X2 = T2 - l2, X3 = T3 - l3, X4 = T4 - l4, X5 = T5 - l5;
-        const uint32_t key = min(min(min((X0 << 3) | 7u, (X1 << 3) | 6u), min((X2 << 3) | 5u, (X3 << 3) | 4u)),
-                                 min((X4 << 3) | 3u, (X5 << 3) | 2u));
-        const uint32_t cand = 7u - (key & 7u);
-        const uint64_t hm = __ballot(lane >= lo && mn > 1024u);
-        if (hm == 0) {
-            if (lane >= lo) kk = cand;
-            break;
+        const uint32_t nxt = gb + nwaves;
+        const bool more = nxt < nblocks;
+        uint4 na = sa, nbv = sb;
+        uint32_t ne = 0, npix = 0xFFFFFFFFu;
+        if (more) {
+            na = st[(uint64_t)nxt * 2];
+            nbv = st[(uint64_t)nxt * 2 + 1];
+            ne = (uint32_t)sorted_e[(uint64_t)nxt * 64 + lane];
+            npix = pix_of[(uint64_t)nxt * 64 + lane];
         }
-        const uint32_t f = (uint32_t)__ffsll((long long)hm) - 1u;
-        if (lane >= lo && lane <= f) kk = cand;
-        const uint32_t f0 = readlane(P0, f), f1 = readlane(P1, f), f2 = readlane(P2, f);
-        const uint32_t f3 = readlane(P3, f), f4 = readlane(P4, f), f5 = readlane(P5, f);
-        S0 = ((S0 + f0) >> 1) - f0; S1 = ((S1 + f1) >> 1) - f1; S2 = ((S2 + f2) >> 1) - f2;
-        S3 = ((S3 + f3) >> 1) - f3; S4 = ((S4 + f4) >> 1) - f4; S5 = ((S5 + f5) >> 1) - f5;
-        lo = f + 1;
-        if (lo >= 64) break;
+        uint32_t S0 = sa.x, S1 = sa.y, S2 = sa.z, S3 = sa.w, S4 = sb.x, S5 = sb.y;
+        uint32_t l01, l23, l45;
+        packed_lengths(e, l01, l23, l45);
+        const uint32_t p01 = wave_incl_scan(l01), p23 = wave_incl_scan(l23), p45 = wave_incl_scan(l45);
+        const uint32_t P0 = p01 & 0xFFFFu, P1 = p01 >> 16, P2 = p23 & 0xFFFFu, P3 = p23 >> 16;
+        const uint32_t P4 = p45 & 0xFFFFu, P5 = p45 >> 16;
+        const uint32_t l0 = l01 & 0xFFFFu, l1 = l01 >> 16, l2 = l23 & 0xFFFFu, l3 = l23 >> 16, l4 = l45 & 0xFFFFu,
+                       l5 = l45 >> 16;
+        uint32_t kk = 0, lo = 0;
+        while (true) {
+            const uint32_t T0 = S0 + P0, T1 = S1 + P1, T2 = S2 + P2, T3 = S3 + P3, T4 = S4 + P4, T5 = S5 + P5;
+            const uint32_t mn = min(min(min(T0, T1), min(T2, T3)), min(T4, T5));
+            // state BEFORE this lane's event -> its k (get_k precedes update, compression.rs:127,139)
+            const uint32_t X0 = T0 - l0, X1 = T1 - l1, X2 = T2 - l2, X3 = T3 - l3, X4 = T4 - l4, X5 = T5 - l5;
+            const uint32_t key = min(min(min((X0 << 3) | 7u, (X1 << 3) | 6u), min((X2 << 3) | 5u, (X3 << 3) | 4u)),
+                                     min((X4 << 3) | 3u, (X5 << 3) | 2u));
+            const uint32_t cand = 7u - (key & 7u);
+            const uint64_t hm = __ballot(lane >= lo && mn > 1024u);
+            if (hm == 0) {
+                if (lane >= lo) kk = cand;
+                break;
+            }
+            const uint32_t f = (uint32_t)__ffsll((long long)hm) - 1u;
+            if (lane >= lo && lane <= f) kk = cand;
+            const uint32_t f0 = readlane(P0, f), f1 = readlane(P1, f), f2 = readlane(P2, f);
+            const uint32_t f3 = readlane(P3, f), f4 = readlane(P4, f), f5 = readlane(P5, f);
+            S0 = ((S0 + f0) >> 1) - f0; S1 = ((S1 + f1) >> 1) - f1; S2 = ((S2 + f2) >> 1) - f2;
+            S3 = ((S3 + f3) >> 1) - f3; S4 = ((S4 + f4) >> 1) - f4; S5 = ((S5 + f5) >> 1) - f5;
+            lo = f + 1;
+            if (lo >= 64) break;
+        }
+        if (pix != 0xFFFFFFFFu) k_map[pix] = (uint8_t)kk;
+        if (!more) break;
+        gb = nxt;
+        sa = na;
+        sb = nbv;
+        e = ne;
+        pix = npix;
     }
-    const uint32_t pix = pix_of[(uint64_t)gb * 64 + lane];
-    if (pix != 0xFFFFFFFFu) k_map[pix] = (uint8_t)kk;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -977,9 +1008,10 @@ template void launch_spine<uint16_t>(hipStream_t, uint16_t *, uint32_t *, uint32
 template <typename ET>
 void launch_assign(hipStream_t s, const ET *sorted_e, const uint32_t *pix_of, uint8_t *k_map,
                    const uint32_t *block_state, const uint32_t *total_slots, const Geometry &g) {
+    // persistent: 8 workgroups of 4 waves per CU walk all blocks (fewer if there cannot be that many blocks)
     const uint32_t max_blocks = max_event_blocks(g);
-    hipLaunchKernelGGL((k_assign<ET>), dim3(cdiv(max_blocks, 4)), dim3(256), 0, s, sorted_e, block_state, pix_of, k_map,
-                       total_slots);
+    const uint32_t wgs = std::min<uint32_t>(cdiv(max_blocks, 4), 256u * 8u);
+    hipLaunchKernelGGL((k_assign<ET>), dim3(wgs), dim3(256), 0, s, sorted_e, block_state, pix_of, k_map, total_slots);
 }
 template void launch_assign<uint8_t>(hipStream_t, const uint8_t *, const uint32_t *, uint8_t *, const uint32_t *,
                                      const uint32_t *, const Geometry &);

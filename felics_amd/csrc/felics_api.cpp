@@ -19,6 +19,7 @@ namespace {
 enum Stage { ST_PLANES = 0, ST_HIST, ST_OFFSETS, ST_SCATTER, ST_SPINE, ST_ASSIGN, ST_LENGTHS, ST_BITSCAN, ST_ZERO, ST_PACK, ST_COUNT };
 const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "spine", "assign", "lengths", "bitscan", "zero", "pack"};
 
+constexpr int SLICES = 4;               // scatter / spine slices per lane: the spine starts after the first quarter
 constexpr int MAX_LANES = 3;            // sub-batches in flight, one HIP stream each (ROCm maps streams onto 4 hardware queues; the caller usually owns one)
 constexpr size_t MIN_LANE_IMAGES = 8;   // below this a sub-batch does not fill the GPU
 
@@ -31,14 +32,16 @@ struct DevBuf {
 // Rice-parameter estimator (k_spine) is a handful of long sequential waves; with several lanes the
 // data-parallel kernels of one sub-batch run underneath the spine of another.
 struct Lane {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // spine, assign, lengths, bit scan, pack
+    hipStream_t front = nullptr;       // planes, hist, offsets, scatter slices
+    hipEvent_t slice_done[SLICES] = {};
     hipEvent_t ev[ST_COUNT][2] = {};
     bool ev_used[ST_COUNT] = {};
     hipEvent_t sized = nullptr;       // stream sizes have landed in h_sizes
     uint64_t *h_sizes = nullptr;      // pinned: image_bytes[n] followed by image_off[n + 1]
     size_t h_sizes_cap = 0;
-    DevBuf planes, counts, chain_len, chain_base, scalars, sorted_e, pix_of, k_map, block_state, group_bits, tile_bits,
-        tile_bitoff, image_bytes, image_off;
+    DevBuf planes, counts, chain_len, chain_base, chain_prog, scalars, sorted_e, pix_of, k_map, block_state, group_bits,
+        tile_bits, tile_bitoff, image_bytes, image_off;
     // the sub-batch in flight
     Geometry g;
     size_t first_image = 0;
@@ -72,8 +75,10 @@ int hip_fail(felics_ctx *ctx, hipError_t e, const char *what) {
     } while (0)
 
 int sync_all(felics_ctx *ctx) {
-    for (Lane &l : ctx->lanes)
+    for (Lane &l : ctx->lanes) {
+        if (l.front) HIP_TRY(ctx, hipStreamSynchronize(l.front));
         if (l.stream) HIP_TRY(ctx, hipStreamSynchronize(l.stream));
+    }
     return FELICS_OK;
 }
 
@@ -101,14 +106,15 @@ struct StageTimer {
     felics_ctx *ctx;
     Lane &lane;
     int st;
-    StageTimer(felics_ctx *c, Lane &l, int s) : ctx(c), lane(l), st(s) {
+    hipStream_t stream;
+    StageTimer(felics_ctx *c, Lane &l, int s, hipStream_t on) : ctx(c), lane(l), st(s), stream(on) {
         if (ctx->profiling) {
-            (void)hipEventRecord(lane.ev[st][0], lane.stream);
+            (void)hipEventRecord(lane.ev[st][0], stream);
             lane.ev_used[st] = true;
         }
     }
     ~StageTimer() {
-        if (ctx->profiling) (void)hipEventRecord(lane.ev[st][1], lane.stream);
+        if (ctx->profiling) (void)hipEventRecord(lane.ev[st][1], stream);
     }
 };
 
@@ -141,6 +147,7 @@ int analyse(felics_ctx *ctx, Lane &l) {
     if ((rc = reserve(ctx, l.counts, (size_t)g.nplanes * g.sort_tiles * NCTX * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.chain_len, (size_t)g.nplanes * NCTX * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.chain_base, (size_t)g.nplanes * NCTX * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.chain_prog, (size_t)g.nplanes * NCTX * 32)) != 0) return rc;
     if ((rc = reserve(ctx, l.scalars, 64)) != 0) return rc;
     if ((rc = reserve(ctx, l.sorted_e, slots * sizeof(ET) + SORTED_PAD)) != 0) return rc;
     if ((rc = reserve(ctx, l.pix_of, slots * 4)) != 0) return rc;
@@ -159,39 +166,55 @@ int analyse(felics_ctx *ctx, Lane &l) {
         l.h_sizes_cap = hs;
     }
 
-    hipStream_t s = l.stream;
+    hipStream_t s = l.stream, f = l.front;
     const T *d_planes = (const T *)l.d_planes;
     auto *counts = (uint32_t *)l.counts.p;
     auto *chain_len = (uint32_t *)l.chain_len.p;
     auto *chain_base = (uint32_t *)l.chain_base.p;
+    auto *chain_prog = (uint32_t *)l.chain_prog.p;
+    // front stream: classification, chain directory, then the events slice by slice
     {
-        StageTimer t(ctx, l, ST_HIST);
-        launch_hist<T>(s, d_planes, counts, g);
+        StageTimer t(ctx, l, ST_HIST, f);
+        launch_hist<T>(f, d_planes, counts, g);
     }
     {
-        StageTimer t(ctx, l, ST_OFFSETS);
-        launch_offsets(s, counts, chain_len, chain_base, (uint32_t *)l.scalars.p, g);
+        StageTimer t(ctx, l, ST_OFFSETS, f);
+        launch_offsets(f, counts, chain_len, chain_base, (uint32_t *)l.scalars.p, g);
+        launch_zero_padding<ET>(f, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, chain_base, chain_len, g);
+        HIP_TRY(ctx, hipMemsetAsync(chain_prog, 0, (size_t)g.nplanes * NCTX * 32, f));
+    }
+    uint32_t bounds[SLICES + 1];
+    for (int q = 0; q <= SLICES; q++) bounds[q] = (uint32_t)((uint64_t)g.sort_tiles * q / SLICES);
+    {
+        StageTimer t(ctx, l, ST_SCATTER, f);
+        for (int q = 0; q < SLICES; q++) {
+            launch_scatter<T, ET>(f, d_planes, counts, chain_base, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, g,
+                                  bounds[q], bounds[q + 1]);
+            HIP_TRY(ctx, hipEventRecord(l.slice_done[q], f));
+        }
+    }
+    // back stream: the spine follows the scatter slices, one launch per slice
+    HIP_TRY(ctx, hipStreamWaitEvent(s, l.slice_done[0], 0));
+    {
+        StageTimer t(ctx, l, ST_SPINE, s);
+        for (int q = 0; q < SLICES; q++) {
+            if (q) HIP_TRY(ctx, hipStreamWaitEvent(s, l.slice_done[q], 0));
+            if (bounds[q + 1] == bounds[q] && q + 1 < SLICES) continue;
+            launch_spine<ET>(s, (const ET *)l.sorted_e.p, (uint32_t *)l.block_state.p, chain_base, chain_len, counts,
+                             bounds[q + 1], chain_prog, g);
+        }
     }
     {
-        StageTimer t(ctx, l, ST_SCATTER);
-        launch_scatter<T, ET>(s, d_planes, counts, chain_base, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, g);
-    }
-    {
-        StageTimer t(ctx, l, ST_SPINE);
-        launch_spine<ET>(s, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, (uint32_t *)l.block_state.p, chain_base,
-                         chain_len, g);
-    }
-    {
-        StageTimer t(ctx, l, ST_ASSIGN);
+        StageTimer t(ctx, l, ST_ASSIGN, s);
         launch_assign<ET>(s, (const ET *)l.sorted_e.p, (const uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
                           (const uint32_t *)l.block_state.p, (const uint32_t *)l.scalars.p, g);
     }
     {
-        StageTimer t(ctx, l, ST_LENGTHS);
+        StageTimer t(ctx, l, ST_LENGTHS, s);
         launch_lengths<T>(s, d_planes, (const uint8_t *)l.k_map.p, (uint16_t *)l.group_bits.p, (uint32_t *)l.tile_bits.p, g);
     }
     {
-        StageTimer t(ctx, l, ST_BITSCAN);
+        StageTimer t(ctx, l, ST_BITSCAN, s);
         launch_bitscan(s, (const uint32_t *)l.tile_bits.p, (uint64_t *)l.tile_bitoff.p, (uint64_t *)l.image_bytes.p,
                        (uint64_t *)l.image_off.p, g);
     }
@@ -207,11 +230,11 @@ int emit(felics_ctx *ctx, Lane &l, uint8_t *d_out) {
     const Geometry &g = l.g;
     hipStream_t s = l.stream;
     {
-        StageTimer t(ctx, l, ST_ZERO);
+        StageTimer t(ctx, l, ST_ZERO, s);
         launch_zero_streams(s, (uint32_t *)d_out, (const uint64_t *)l.image_off.p, g);
     }
     {
-        StageTimer t(ctx, l, ST_PACK);
+        StageTimer t(ctx, l, ST_PACK, s);
         launch_pack<T>(s, (const T *)l.d_planes, (const uint8_t *)l.k_map.p, (const uint16_t *)l.group_bits.p,
                        (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p,
                        (const uint64_t *)l.image_off.p, d_out, g);
@@ -312,8 +335,8 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
             l.d_planes = src;
             if (planes == 3) {
                 if ((rc = reserve(ctx, l.planes, (size_t)g.nplanes * npix * 2 + STAGE_PAD)) != 0) return rc;
-                StageTimer t(ctx, l, ST_PLANES);
-                launch_rgb8_to_planes(l.stream, src, (int16_t *)l.planes.p, g.npix, g.nimages);
+                StageTimer t(ctx, l, ST_PLANES, l.front);
+                launch_rgb8_to_planes(l.front, src, (int16_t *)l.planes.p, g.npix, g.nimages);
                 l.d_planes = l.planes.p;
             }
             rc = planes == 3 ? analyse<int16_t, uint16_t>(ctx, l) : analyse<uint8_t, uint8_t>(ctx, l);
@@ -389,6 +412,9 @@ int felics_ctx_create(int device, felics_ctx **out) {
     bool ok = hipSetDevice(device) == hipSuccess;
     for (Lane &l : ctx->lanes) {
         ok = ok && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&l.front, hipStreamNonBlocking) == hipSuccess;
+        for (int q = 0; q < SLICES && ok; q++)
+            ok = hipEventCreateWithFlags(&l.slice_done[q], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&l.sized, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < ST_COUNT && ok; i++)
             for (int j = 0; j < 2 && ok; j++) ok = hipEventCreate(&l.ev[i][j]) == hipSuccess;
@@ -405,8 +431,9 @@ void felics_ctx_destroy(felics_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (Lane &l : ctx->lanes) {
+        if (l.front) (void)hipStreamSynchronize(l.front);
         if (l.stream) (void)hipStreamSynchronize(l.stream);
-        DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map,
+        DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map,
                           &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.image_bytes, &l.image_off};
         for (DevBuf *b : bufs) release(*b);
         if (l.h_sizes) (void)hipHostFree(l.h_sizes);
@@ -414,6 +441,9 @@ void felics_ctx_destroy(felics_ctx *ctx) {
             for (int j = 0; j < 2; j++)
                 if (l.ev[i][j]) (void)hipEventDestroy(l.ev[i][j]);
         if (l.sized) (void)hipEventDestroy(l.sized);
+        for (int q = 0; q < SLICES; q++)
+            if (l.slice_done[q]) (void)hipEventDestroy(l.slice_done[q]);
+        if (l.front) (void)hipStreamDestroy(l.front);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     release(ctx->in);

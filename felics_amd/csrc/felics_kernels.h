@@ -39,9 +39,10 @@ void launch_hist(hipStream_t s, const T *planes, uint32_t *counts, const Geometr
 void launch_offsets(hipStream_t s, uint32_t *counts, uint32_t *chain_len, uint32_t *chain_base,
                     uint32_t *total_events, const Geometry &g);
 
+// scatter works on a slice [tile_begin, tile_end) of every plane's tiles
 template <typename T, typename ET>
 void launch_scatter(hipStream_t s, const T *planes, const uint32_t *tile_off, const uint32_t *chain_base,
-                    ET *sorted_e, uint32_t *pix_of, const Geometry &g);
+                    ET *sorted_e, uint32_t *pix_of, const Geometry &g, uint32_t tile_begin, uint32_t tile_end);
 
 // Chains are padded to whole 64-event blocks: upper bounds of the slot / block counts of a pass.
 inline uint64_t max_event_slots(const Geometry &g) {
@@ -54,10 +55,18 @@ constexpr size_t SORTED_PAD = 64 * 64 * 2 + 256;
 // k_map / plane buffers are read in whole 16-byte chunks by the tile staging
 constexpr size_t STAGE_PAD = 64;
 
-// resolve = spine (sequential per chain: state at every 64-event block) + assign (k of every event)
+// resolve = spine (sequential per chain: state at every 64-event block) + assign (k of every event).
+// The spine is resumable: launched once per scatter slice with t_end = the slice's last tile + 1, it
+// advances every chain over the blocks whose events are already in place (chain_prog: 8 u32 per chain,
+// zeroed before the first launch).
 template <typename ET>
-void launch_spine(hipStream_t s, ET *sorted_e, uint32_t *pix_of, uint32_t *block_state, const uint32_t *chain_base,
-                  const uint32_t *chain_len, const Geometry &g);
+void launch_zero_padding(hipStream_t s, ET *sorted_e, uint32_t *pix_of, const uint32_t *chain_base,
+                         const uint32_t *chain_len, const Geometry &g);
+
+template <typename ET>
+void launch_spine(hipStream_t s, const ET *sorted_e, uint32_t *block_state, const uint32_t *chain_base,
+                  const uint32_t *chain_len, const uint32_t *tile_off, uint32_t t_end, uint32_t *chain_prog,
+                  const Geometry &g);
 
 template <typename ET>
 void launch_assign(hipStream_t s, const ET *sorted_e, const uint32_t *pix_of, uint8_t *k_map,

@@ -260,12 +260,13 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
                                                  const uint32_t *__restrict__ tile_off,
                                                  const uint32_t *__restrict__ chain_base,
                                                  ET *__restrict__ sorted_e, uint32_t *__restrict__ pix_of,
-                                                 uint32_t W, uint32_t npix, uint32_t ntiles) {
+                                                 uint32_t W, uint32_t npix, uint32_t ntiles, uint32_t tile_begin,
+                                                 uint32_t tile_end) {
     __shared__ uint32_t runs[4][NCTX];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t tile = blockIdx.x * 4 + wave;
+    const uint32_t tile = tile_begin + blockIdx.x * 4 + wave;
     const uint32_t plane = blockIdx.y;
-    if (tile >= ntiles) return;
+    if (tile >= tile_end) return;
     uint32_t *run = runs[wave];
     {
         const uint32_t *off = tile_off + ((uint64_t)plane * ntiles + tile) * NCTX;
@@ -380,7 +381,9 @@ constexpr uint32_t SPINE_BATCH = 64;  // blocks fetched per step: lane j holds b
 template <typename ET>
 __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, uint32_t *__restrict__ block_state,
                                               const uint32_t *__restrict__ chain_base,
-                                              const uint32_t *__restrict__ chain_len, uint32_t nchains) {
+                                              const uint32_t *__restrict__ chain_len, uint32_t nchains,
+                                              const uint32_t *__restrict__ tile_off, uint32_t ntiles, uint32_t t_end,
+                                              uint32_t *__restrict__ chain_prog) {
     constexpr uint32_t DW = 64 * sizeof(ET) / 4;  // dwords per block
     __shared__ uint32_t stage[SPINE_BATCH * DW];          // the batch's events
     __shared__ uint32_t bsum[(SPINE_BATCH + 1) * 8];      // [block][k]: sum of the block's lengths for k = 0..5
@@ -389,27 +392,35 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
     // planes start first and land on different XCDs (workgroups are dealt round-robin over the XCDs).
     if (blockIdx.x >= nchains) return;
     const uint32_t nplanes = nchains / NCTX;
-    const uint32_t chain = (blockIdx.x % nplanes) * NCTX + blockIdx.x / nplanes;
+    const uint32_t ctx = blockIdx.x / nplanes, plane = blockIdx.x % nplanes;
+    const uint32_t chain = plane * NCTX + ctx;
     const uint32_t n = chain_len[chain];
     if (n == 0) return;
     const uint32_t lane = lane_id();
     const uint32_t l7 = lane & 7u;
+    // The kernel is launched once per slice of tiles, as soon as that slice's events have been
+    // scattered: it resumes every chain at chain_prog and stops at the last whole block whose events
+    // all come from tiles < t_end (the final launch, t_end = ntiles, also takes the partial block).
+    const uint32_t nblocks = t_end >= ntiles ? (n + 63u) >> 6
+                                             : tile_off[((uint64_t)plane * ntiles + t_end) * NCTX + ctx] >> 6;
+    uint32_t *prog = chain_prog + (uint64_t)chain * 8;  // [0] next block, [1..6] state
+    const uint32_t first_block = prog[0];
+    if (first_block >= nblocks) return;
     __builtin_amdgcn_s_setprio(3);  // a chain is one long dependent instruction stream: never make it wait for issue
     const uint32_t base = chain_base[chain];  // multiple of 64
-    const uint32_t nblocks = (n + 63u) >> 6;
     const uint4 *src = reinterpret_cast<const uint4 *>(sorted_e + base);  // block b = DW/4 uint4 at b*DW/4
     uint4 *states = reinterpret_cast<uint4 *>(block_state) + (uint64_t)(base >> 6) * 2;
 
     uint4 buf[DW / 4];
-    if (lane < nblocks) {
+    if (first_block + lane < nblocks) {
 #pragma unroll
-        for (uint32_t q = 0; q < DW / 4; q++) buf[q] = src[(uint64_t)lane * (DW / 4) + q];
+        for (uint32_t q = 0; q < DW / 4; q++) buf[q] = src[(uint64_t)(first_block + lane) * (DW / 4) + q];
     }
     if (lane < 8) bsum[SPINE_BATCH * 8 + lane] = 0;  // read (and ignored) by the look-ahead of the last block
     // The state lives in a VGPR: lane l holds S[l & 7] (entries 6, 7 unused).  Stepping over a block
     // without a halving is then one LDS read, one add and one compare for all six counters.
-    uint32_t Sv = 0;
-    for (uint32_t bb = 0; bb < nblocks; bb += SPINE_BATCH) {
+    uint32_t Sv = l7 < 6 ? prog[1 + l7] : 0u;
+    for (uint32_t bb = first_block; bb < nblocks; bb += SPINE_BATCH) {
         const uint32_t nb = min(SPINE_BATCH, nblocks - bb);
         // lane j: sums of block bb + j, constant part 64 * (1 + k) included; events copied to LDS
         if (lane < nb) {
@@ -480,6 +491,8 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
         }
         __syncthreads();
     }
+    if (lane < 6) prog[1 + lane] = Sv;
+    if (lane == 6) prog[0] = nblocks;
 }
 
 // One wave per 64-event block (chains are 64-aligned, so a block never straddles two chains):
@@ -982,28 +995,40 @@ void launch_offsets(hipStream_t s, uint32_t *counts, uint32_t *chain_len, uint32
 
 template <typename T, typename ET>
 void launch_scatter(hipStream_t s, const T *planes, const uint32_t *tile_off, const uint32_t *chain_base,
-                    ET *sorted_e, uint32_t *pix_of, const Geometry &g) {
-    hipLaunchKernelGGL((k_scatter<T, ET>), dim3(cdiv(g.sort_tiles, 4), g.nplanes), dim3(256), 0, s, planes,
-                       tile_off, chain_base, sorted_e, pix_of, g.W, g.npix, g.sort_tiles);
+                    ET *sorted_e, uint32_t *pix_of, const Geometry &g, uint32_t tile_begin, uint32_t tile_end) {
+    if (tile_end <= tile_begin) return;
+    hipLaunchKernelGGL((k_scatter<T, ET>), dim3(cdiv(tile_end - tile_begin, 4), g.nplanes), dim3(256), 0, s, planes,
+                       tile_off, chain_base, sorted_e, pix_of, g.W, g.npix, g.sort_tiles, tile_begin, tile_end);
 }
 template void launch_scatter<uint8_t, uint8_t>(hipStream_t, const uint8_t *, const uint32_t *, const uint32_t *,
-                                               uint8_t *, uint32_t *, const Geometry &);
+                                               uint8_t *, uint32_t *, const Geometry &, uint32_t, uint32_t);
 template void launch_scatter<int16_t, uint16_t>(hipStream_t, const int16_t *, const uint32_t *, const uint32_t *,
-                                                uint16_t *, uint32_t *, const Geometry &);
+                                                uint16_t *, uint32_t *, const Geometry &, uint32_t, uint32_t);
 
 template <typename ET>
-void launch_spine(hipStream_t s, ET *sorted_e, uint32_t *pix_of, uint32_t *block_state, const uint32_t *chain_base,
-                  const uint32_t *chain_len, const Geometry &g) {
+void launch_zero_padding(hipStream_t s, ET *sorted_e, uint32_t *pix_of, const uint32_t *chain_base,
+                         const uint32_t *chain_len, const Geometry &g) {
     const uint32_t nchains = g.nplanes * NCTX;
     hipLaunchKernelGGL((k_zero_padding<ET>), dim3(cdiv(nchains, 256)), dim3(256), 0, s, sorted_e, pix_of, chain_base,
                        chain_len, nchains);
-    hipLaunchKernelGGL((k_spine<ET>), dim3(nchains), dim3(64), 0, s, (const ET *)sorted_e, block_state, chain_base,
-                       chain_len, nchains);
 }
-template void launch_spine<uint8_t>(hipStream_t, uint8_t *, uint32_t *, uint32_t *, const uint32_t *,
-                                    const uint32_t *, const Geometry &);
-template void launch_spine<uint16_t>(hipStream_t, uint16_t *, uint32_t *, uint32_t *, const uint32_t *,
-                                     const uint32_t *, const Geometry &);
+template void launch_zero_padding<uint8_t>(hipStream_t, uint8_t *, uint32_t *, const uint32_t *, const uint32_t *,
+                                           const Geometry &);
+template void launch_zero_padding<uint16_t>(hipStream_t, uint16_t *, uint32_t *, const uint32_t *, const uint32_t *,
+                                            const Geometry &);
+
+template <typename ET>
+void launch_spine(hipStream_t s, const ET *sorted_e, uint32_t *block_state, const uint32_t *chain_base,
+                  const uint32_t *chain_len, const uint32_t *tile_off, uint32_t t_end, uint32_t *chain_prog,
+                  const Geometry &g) {
+    const uint32_t nchains = g.nplanes * NCTX;
+    hipLaunchKernelGGL((k_spine<ET>), dim3(nchains), dim3(64), 0, s, sorted_e, block_state, chain_base, chain_len,
+                       nchains, tile_off, g.sort_tiles, t_end, chain_prog);
+}
+template void launch_spine<uint8_t>(hipStream_t, const uint8_t *, uint32_t *, const uint32_t *, const uint32_t *,
+                                    const uint32_t *, uint32_t, uint32_t *, const Geometry &);
+template void launch_spine<uint16_t>(hipStream_t, const uint16_t *, uint32_t *, const uint32_t *, const uint32_t *,
+                                     const uint32_t *, uint32_t, uint32_t *, const Geometry &);
 
 template <typename ET>
 void launch_assign(hipStream_t s, const ET *sorted_e, const uint32_t *pix_of, uint8_t *k_map,

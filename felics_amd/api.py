@@ -108,6 +108,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # libfelics overlaps kernels on four HIP streams; give them hardware queues of their own
+    # (ROCm default: 4 per process).  Read by the HIP runtime when it initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     _share_hip_runtime()
     L = C.CDLL(_build.ensure_lib())
     vp, sz = C.c_void_p, C.c_size_t

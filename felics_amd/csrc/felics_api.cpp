@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -19,8 +20,8 @@ namespace {
 enum Stage { ST_PLANES = 0, ST_HIST, ST_OFFSETS, ST_SCATTER, ST_SPINE, ST_ASSIGN, ST_LENGTHS, ST_BITSCAN, ST_ZERO, ST_PACK, ST_COUNT };
 const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "spine", "assign", "lengths", "bitscan", "zero", "pack"};
 
-constexpr int SLICES = 4;               // scatter / spine slices per lane: the spine starts after the first quarter
-constexpr int MAX_LANES = 3;            // sub-batches in flight, one HIP stream each (ROCm maps streams onto 4 hardware queues; the caller usually owns one)
+constexpr int SLICES = 6;               // scatter / spine slices per lane: the spine starts after the first quarter
+constexpr int MAX_LANES = 2;            // sub-batches in flight, two HIP streams each
 constexpr size_t MIN_LANE_IMAGES = 8;   // below this a sub-batch does not fill the GPU
 
 struct DevBuf {
@@ -52,6 +53,7 @@ struct Lane {
 
 struct felics_ctx {
     int device = -1;
+    int max_lanes = MAX_LANES;  // FELICS_LANES=1..MAX_LANES overrides (tuning / per-kernel timing)
     Lane lanes[MAX_LANES];
     std::string err;
     bool profiling = false;
@@ -309,7 +311,7 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
     // lanes' data-parallel kernels), then place and pack the streams in image order.
     while (done < n) {
         const size_t left = n - done;
-        const size_t nl = std::min<size_t>(MAX_LANES, std::max<size_t>(1, left / MIN_LANE_IMAGES));
+        const size_t nl = std::min<size_t>((size_t)ctx->max_lanes, std::max<size_t>(1, left / MIN_LANE_IMAGES));
         // Later lanes get fewer images (weights nl, nl-1, .., 1): every lane pays the same spine
         // latency, so the lane that starts last should have the least work left after its spine.
         const size_t wsum = nl * (nl + 1) / 2;
@@ -409,6 +411,13 @@ int felics_ctx_create(int device, felics_ctx **out) {
     felics_ctx *ctx = new (std::nothrow) felics_ctx();
     if (!ctx) return FELICS_E_IO;
     ctx->device = device;
+    // Four streams want four hardware queues of their own; ROCm's default is 4 per process and the
+    // caller's stream takes one.  Only effective if the HIP runtime has not been initialised yet.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    if (const char *e = getenv("FELICS_LANES")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= MAX_LANES) ctx->max_lanes = v;
+    }
     bool ok = hipSetDevice(device) == hipSuccess;
     for (Lane &l : ctx->lanes) {
         ok = ok && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess;

@@ -21,7 +21,7 @@ enum Stage { ST_PLANES = 0, ST_HIST, ST_OFFSETS, ST_SCATTER, ST_SPINE, ST_ASSIGN
 const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "spine", "assign", "lengths", "bitscan", "zero", "pack"};
 
 constexpr int SLICES = 6;               // scatter / spine slices per lane: the spine starts after the first quarter
-constexpr int MAX_LANES = 2;            // sub-batches in flight, two HIP streams each
+constexpr int MAX_LANES = 2;            // sub-batches in flight, three HIP streams each (front, spine, tail)
 constexpr size_t MIN_LANE_IMAGES = 8;   // below this a sub-batch does not fill the GPU
 
 struct DevBuf {
@@ -33,9 +33,11 @@ struct DevBuf {
 // Rice-parameter estimator (k_spine) is a handful of long sequential waves; with several lanes the
 // data-parallel kernels of one sub-batch run underneath the spine of another.
 struct Lane {
-    hipStream_t stream = nullptr;      // spine, assign, lengths, bit scan, pack
+    hipStream_t stream = nullptr;      // spine slices
     hipStream_t front = nullptr;       // planes, hist, offsets, scatter slices
+    hipStream_t tail = nullptr;        // assign slices, lengths, bit scan, pack
     hipEvent_t slice_done[SLICES] = {};
+    hipEvent_t spine_done[SLICES] = {};
     hipEvent_t ev[ST_COUNT][2] = {};
     bool ev_used[ST_COUNT] = {};
     hipEvent_t sized = nullptr;       // stream sizes have landed in h_sizes
@@ -54,6 +56,7 @@ struct Lane {
 struct felics_ctx {
     int device = -1;
     int max_lanes = MAX_LANES;  // FELICS_LANES=1..MAX_LANES overrides (tuning / per-kernel timing)
+    uint32_t epoch = 0;         // submission counter: block records are stamped (epoch, slice)
     Lane lanes[MAX_LANES];
     std::string err;
     bool profiling = false;
@@ -80,6 +83,7 @@ int sync_all(felics_ctx *ctx) {
     for (Lane &l : ctx->lanes) {
         if (l.front) HIP_TRY(ctx, hipStreamSynchronize(l.front));
         if (l.stream) HIP_TRY(ctx, hipStreamSynchronize(l.stream));
+        if (l.tail) HIP_TRY(ctx, hipStreamSynchronize(l.tail));
     }
     return FELICS_OK;
 }
@@ -170,6 +174,7 @@ int analyse(felics_ctx *ctx, Lane &l) {
 
     hipStream_t s = l.stream, f = l.front;
     const T *d_planes = (const T *)l.d_planes;
+    ctx->epoch++;
     auto *counts = (uint32_t *)l.counts.p;
     auto *chain_len = (uint32_t *)l.chain_len.p;
     auto *chain_base = (uint32_t *)l.chain_base.p;
@@ -195,22 +200,33 @@ int analyse(felics_ctx *ctx, Lane &l) {
             HIP_TRY(ctx, hipEventRecord(l.slice_done[q], f));
         }
     }
-    // back stream: the spine follows the scatter slices, one launch per slice
+    // spine stream: follows the scatter slices, one launch per slice; tail stream: k of the events each
+    // spine launch made servable, while the spine moves on
+    hipStream_t tl = l.tail;
+    const uint32_t stamp0 = (ctx->epoch & 0x0FFFFFFFu) << 4;
     HIP_TRY(ctx, hipStreamWaitEvent(s, l.slice_done[0], 0));
     {
         StageTimer t(ctx, l, ST_SPINE, s);
         for (int q = 0; q < SLICES; q++) {
             if (q) HIP_TRY(ctx, hipStreamWaitEvent(s, l.slice_done[q], 0));
-            if (bounds[q + 1] == bounds[q] && q + 1 < SLICES) continue;
-            launch_spine<ET>(s, (const ET *)l.sorted_e.p, (uint32_t *)l.block_state.p, chain_base, chain_len, counts,
-                             bounds[q + 1], chain_prog, g);
+            if (bounds[q + 1] != bounds[q] || q + 1 == SLICES)
+                launch_spine<ET>(s, (const ET *)l.sorted_e.p, (uint32_t *)l.block_state.p, chain_base, chain_len, counts,
+                                 bounds[q + 1], chain_prog, stamp0 + (uint32_t)q + 1, g);
+            HIP_TRY(ctx, hipEventRecord(l.spine_done[q], s));
         }
     }
+    HIP_TRY(ctx, hipStreamWaitEvent(tl, l.spine_done[0], 0));
     {
-        StageTimer t(ctx, l, ST_ASSIGN, s);
-        launch_assign<ET>(s, (const ET *)l.sorted_e.p, (const uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
-                          (const uint32_t *)l.block_state.p, (const uint32_t *)l.scalars.p, g);
+        StageTimer t(ctx, l, ST_ASSIGN, tl);
+        for (int q = 0; q < SLICES; q++) {
+            if (q) HIP_TRY(ctx, hipStreamWaitEvent(tl, l.spine_done[q], 0));
+            if (bounds[q + 1] != bounds[q] || q + 1 == SLICES)
+                launch_assign<ET>(tl, (const ET *)l.sorted_e.p, (const uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
+                                  (const uint32_t *)l.block_state.p, (const uint32_t *)l.scalars.p,
+                                  stamp0 + (uint32_t)q + 1, g);
+        }
     }
+    s = tl;  // everything below runs on the tail stream
     {
         StageTimer t(ctx, l, ST_LENGTHS, s);
         launch_lengths<T>(s, d_planes, (const uint8_t *)l.k_map.p, (uint16_t *)l.group_bits.p, (uint32_t *)l.tile_bits.p, g);
@@ -230,7 +246,7 @@ int analyse(felics_ctx *ctx, Lane &l) {
 template <typename T>
 int emit(felics_ctx *ctx, Lane &l, uint8_t *d_out) {
     const Geometry &g = l.g;
-    hipStream_t s = l.stream;
+    hipStream_t s = l.tail;
     {
         StageTimer t(ctx, l, ST_ZERO, s);
         launch_zero_streams(s, (uint32_t *)d_out, (const uint64_t *)l.image_off.p, g);
@@ -422,8 +438,11 @@ int felics_ctx_create(int device, felics_ctx **out) {
     for (Lane &l : ctx->lanes) {
         ok = ok && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipStreamCreateWithFlags(&l.front, hipStreamNonBlocking) == hipSuccess;
-        for (int q = 0; q < SLICES && ok; q++)
+        ok = ok && hipStreamCreateWithFlags(&l.tail, hipStreamNonBlocking) == hipSuccess;
+        for (int q = 0; q < SLICES && ok; q++) {
             ok = hipEventCreateWithFlags(&l.slice_done[q], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&l.spine_done[q], hipEventDisableTiming) == hipSuccess;
+        }
         ok = ok && hipEventCreateWithFlags(&l.sized, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < ST_COUNT && ok; i++)
             for (int j = 0; j < 2 && ok; j++) ok = hipEventCreate(&l.ev[i][j]) == hipSuccess;
@@ -442,6 +461,7 @@ void felics_ctx_destroy(felics_ctx *ctx) {
     for (Lane &l : ctx->lanes) {
         if (l.front) (void)hipStreamSynchronize(l.front);
         if (l.stream) (void)hipStreamSynchronize(l.stream);
+        if (l.tail) (void)hipStreamSynchronize(l.tail);
         DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map,
                           &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.image_bytes, &l.image_off};
         for (DevBuf *b : bufs) release(*b);
@@ -450,9 +470,12 @@ void felics_ctx_destroy(felics_ctx *ctx) {
             for (int j = 0; j < 2; j++)
                 if (l.ev[i][j]) (void)hipEventDestroy(l.ev[i][j]);
         if (l.sized) (void)hipEventDestroy(l.sized);
-        for (int q = 0; q < SLICES; q++)
+        for (int q = 0; q < SLICES; q++) {
             if (l.slice_done[q]) (void)hipEventDestroy(l.slice_done[q]);
+            if (l.spine_done[q]) (void)hipEventDestroy(l.spine_done[q]);
+        }
         if (l.front) (void)hipStreamDestroy(l.front);
+        if (l.tail) (void)hipStreamDestroy(l.tail);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     release(ctx->in);

@@ -66,11 +66,12 @@ void launch_zero_padding(hipStream_t s, ET *sorted_e, uint32_t *pix_of, const ui
 template <typename ET>
 void launch_spine(hipStream_t s, const ET *sorted_e, uint32_t *block_state, const uint32_t *chain_base,
                   const uint32_t *chain_len, const uint32_t *tile_off, uint32_t t_end, uint32_t *chain_prog,
-                  const Geometry &g);
+                  uint32_t stamp, const Geometry &g);
 
 template <typename ET>
+// serves the blocks whose record carries `stamp` (written by the spine launch of the same slice)
 void launch_assign(hipStream_t s, const ET *sorted_e, const uint32_t *pix_of, uint8_t *k_map,
-                   const uint32_t *block_state, const uint32_t *total_slots, const Geometry &g);
+                   const uint32_t *block_state, const uint32_t *total_slots, uint32_t stamp, const Geometry &g);
 
 template <typename T>
 void launch_lengths(hipStream_t s, const T *planes, const uint8_t *k_map, uint16_t *group_bits, uint32_t *tile_bits,

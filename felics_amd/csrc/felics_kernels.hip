@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
                                               const uint32_t *__restrict__ chain_base,
                                               const uint32_t *__restrict__ chain_len, uint32_t nchains,
                                               const uint32_t *__restrict__ tile_off, uint32_t ntiles, uint32_t t_end,
-                                              uint32_t *__restrict__ chain_prog) {
+                                              uint32_t *__restrict__ chain_prog, uint32_t stamp) {
     constexpr uint32_t DW = 64 * sizeof(ET) / 4;  // dwords per block
     __shared__ uint32_t stage[SPINE_BATCH * DW];          // the batch's events
     __shared__ uint32_t bsum[(SPINE_BATCH + 1) * 8];      // [block][k]: sum of the block's lengths for k = 0..5
@@ -401,15 +401,17 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
     // The kernel is launched once per slice of tiles, as soon as that slice's events have been
     // scattered: it resumes every chain at chain_prog and stops at the last whole block whose events
     // all come from tiles < t_end (the final launch, t_end = ntiles, also takes the partial block).
-    const uint32_t nblocks = t_end >= ntiles ? (n + 63u) >> 6
-                                             : tile_off[((uint64_t)plane * ntiles + t_end) * NCTX + ctx] >> 6;
+    const bool final_slice = t_end >= ntiles;
+    const uint32_t avail = final_slice ? n : tile_off[((uint64_t)plane * ntiles + t_end) * NCTX + ctx];  // events in place
+    const uint32_t nblocks = final_slice ? (n + 63u) >> 6 : avail >> 6;
     uint32_t *prog = chain_prog + (uint64_t)chain * 8;  // [0] next block, [1..6] state
     const uint32_t first_block = prog[0];
-    if (first_block >= nblocks) return;
-    __builtin_amdgcn_s_setprio(3);  // a chain is one long dependent instruction stream: never make it wait for issue
     const uint32_t base = chain_base[chain];  // multiple of 64
     const uint4 *src = reinterpret_cast<const uint4 *>(sorted_e + base);  // block b = DW/4 uint4 at b*DW/4
     uint4 *states = reinterpret_cast<uint4 *>(block_state) + (uint64_t)(base >> 6) * 2;
+    uint32_t Sv = l7 < 6 ? prog[1 + l7] : 0u;
+    if (first_block < nblocks) {
+    __builtin_amdgcn_s_setprio(3);  // a chain is one long dependent instruction stream: never make it wait for issue
 
     uint4 buf[DW / 4];
     if (first_block + lane < nblocks) {
@@ -419,7 +421,6 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
     if (lane < 8) bsum[SPINE_BATCH * 8 + lane] = 0;  // read (and ignored) by the look-ahead of the last block
     // The state lives in a VGPR: lane l holds S[l & 7] (entries 6, 7 unused).  Stepping over a block
     // without a halving is then one LDS read, one add and one compare for all six counters.
-    uint32_t Sv = l7 < 6 ? prog[1 + l7] : 0u;
     for (uint32_t bb = first_block; bb < nblocks; bb += SPINE_BATCH) {
         const uint32_t nb = min(SPINE_BATCH, nblocks - bb);
         // lane j: sums of block bb + j, constant part 64 * (1 + k) included; events copied to LDS
@@ -486,13 +487,25 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
         }
         __syncthreads();
         if (lane < nb) {
+            const uint4 hi = reinterpret_cast<const uint4 *>(rec)[lane * 2 + 1];
             states[(uint64_t)(bb + lane) * 2] = reinterpret_cast<const uint4 *>(rec)[lane * 2];
-            states[(uint64_t)(bb + lane) * 2 + 1] = reinterpret_cast<const uint4 *>(rec)[lane * 2 + 1];
+            states[(uint64_t)(bb + lane) * 2 + 1] = make_uint4(hi.x, hi.y, stamp, 64u);  // a whole block, resolved in this launch
         }
         __syncthreads();
     }
     if (lane < 6) prog[1 + lane] = Sv;
     if (lane == 6) prog[0] = nblocks;
+    }
+    // Events that are in place but do not fill a block yet: publish the block's start state and how many
+    // of its events exist, so k_assign can serve them now (the block is resolved by a later launch).
+    if (!final_slice && (avail & 63u) != 0) {
+        const uint32_t s0 = readlane(Sv, 0), s1 = readlane(Sv, 1), s2 = readlane(Sv, 2);
+        const uint32_t s3 = readlane(Sv, 3), s4 = readlane(Sv, 4), s5 = readlane(Sv, 5);
+        if (lane == 0) {
+            states[(uint64_t)nblocks * 2] = make_uint4(s0, s1, s2, s3);
+            states[(uint64_t)nblocks * 2 + 1] = make_uint4(s4, s5, stamp, avail & 63u);
+        }
+    }
 }
 
 // One wave per 64-event block (chains are 64-aligned, so a block never straddles two chains):
@@ -501,28 +514,28 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
 template <typename ET>
 __global__ __launch_bounds__(256) void k_assign(const ET *__restrict__ sorted_e, const uint32_t *__restrict__ block_state,
                                                 const uint32_t *__restrict__ pix_of, uint8_t *__restrict__ k_map,
-                                                const uint32_t *__restrict__ total_slots) {
+                                                const uint32_t *__restrict__ total_slots, uint32_t stamp) {
     const uint32_t lane = lane_id();
     const uint32_t nblocks = *total_slots >> 6;
     const uint32_t nwaves = gridDim.x * 4;
     uint32_t gb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (gb >= nblocks) return;
-    // grid-stride over the blocks; the next block's inputs are requested before this one is resolved
+    // Grid-stride over the blocks.  Only blocks whose record carries this launch's stamp are served
+    // (written by the spine launch of the same slice); the next record is requested ahead, a block's
+    // events and pixels are only fetched when it is served.  Record: {S0..S3}, {S4, S5, stamp, valid events}.
     const uint4 *st = reinterpret_cast<const uint4 *>(block_state);
     uint4 sa = st[(uint64_t)gb * 2], sb = st[(uint64_t)gb * 2 + 1];
-    uint32_t e = (uint32_t)sorted_e[(uint64_t)gb * 64 + lane];
-    uint32_t pix = pix_of[(uint64_t)gb * 64 + lane];
     while (true) {
         const uint32_t nxt = gb + nwaves;
         const bool more = nxt < nblocks;
         uint4 na = sa, nbv = sb;
-        uint32_t ne = 0, npix = 0xFFFFFFFFu;
         if (more) {
             na = st[(uint64_t)nxt * 2];
             nbv = st[(uint64_t)nxt * 2 + 1];
-            ne = (uint32_t)sorted_e[(uint64_t)nxt * 64 + lane];
-            npix = pix_of[(uint64_t)nxt * 64 + lane];
         }
+        if (sb.z == stamp) {
+        const uint32_t e = (uint32_t)sorted_e[(uint64_t)gb * 64 + lane];
+        const uint32_t pix = pix_of[(uint64_t)gb * 64 + lane];
         uint32_t S0 = sa.x, S1 = sa.y, S2 = sa.z, S3 = sa.w, S4 = sb.x, S5 = sb.y;
         uint32_t l01, l23, l45;
         packed_lengths(e, l01, l23, l45);
@@ -554,13 +567,12 @@ __global__ __launch_bounds__(256) void k_assign(const ET *__restrict__ sorted_e,
             lo = f + 1;
             if (lo >= 64) break;
         }
-        if (pix != 0xFFFFFFFFu) k_map[pix] = (uint8_t)kk;
+        if (lane < sb.w && pix != 0xFFFFFFFFu) k_map[pix] = (uint8_t)kk;
+        }
         if (!more) break;
         gb = nxt;
         sa = na;
         sb = nbv;
-        e = ne;
-        pix = npix;
     }
 }
 
@@ -1020,28 +1032,29 @@ template void launch_zero_padding<uint16_t>(hipStream_t, uint16_t *, uint32_t *,
 template <typename ET>
 void launch_spine(hipStream_t s, const ET *sorted_e, uint32_t *block_state, const uint32_t *chain_base,
                   const uint32_t *chain_len, const uint32_t *tile_off, uint32_t t_end, uint32_t *chain_prog,
-                  const Geometry &g) {
+                  uint32_t stamp, const Geometry &g) {
     const uint32_t nchains = g.nplanes * NCTX;
     hipLaunchKernelGGL((k_spine<ET>), dim3(nchains), dim3(64), 0, s, sorted_e, block_state, chain_base, chain_len,
-                       nchains, tile_off, g.sort_tiles, t_end, chain_prog);
+                       nchains, tile_off, g.sort_tiles, t_end, chain_prog, stamp);
 }
 template void launch_spine<uint8_t>(hipStream_t, const uint8_t *, uint32_t *, const uint32_t *, const uint32_t *,
-                                    const uint32_t *, uint32_t, uint32_t *, const Geometry &);
+                                    const uint32_t *, uint32_t, uint32_t *, uint32_t, const Geometry &);
 template void launch_spine<uint16_t>(hipStream_t, const uint16_t *, uint32_t *, const uint32_t *, const uint32_t *,
-                                     const uint32_t *, uint32_t, uint32_t *, const Geometry &);
+                                     const uint32_t *, uint32_t, uint32_t *, uint32_t, const Geometry &);
 
 template <typename ET>
 void launch_assign(hipStream_t s, const ET *sorted_e, const uint32_t *pix_of, uint8_t *k_map,
-                   const uint32_t *block_state, const uint32_t *total_slots, const Geometry &g) {
+                   const uint32_t *block_state, const uint32_t *total_slots, uint32_t stamp, const Geometry &g) {
     // persistent: 8 workgroups of 4 waves per CU walk all blocks (fewer if there cannot be that many blocks)
     const uint32_t max_blocks = max_event_blocks(g);
     const uint32_t wgs = std::min<uint32_t>(cdiv(max_blocks, 4), 256u * 8u);
-    hipLaunchKernelGGL((k_assign<ET>), dim3(wgs), dim3(256), 0, s, sorted_e, block_state, pix_of, k_map, total_slots);
+    hipLaunchKernelGGL((k_assign<ET>), dim3(wgs), dim3(256), 0, s, sorted_e, block_state, pix_of, k_map, total_slots,
+                       stamp);
 }
 template void launch_assign<uint8_t>(hipStream_t, const uint8_t *, const uint32_t *, uint8_t *, const uint32_t *,
-                                     const uint32_t *, const Geometry &);
+                                     const uint32_t *, uint32_t, const Geometry &);
 template void launch_assign<uint16_t>(hipStream_t, const uint16_t *, const uint32_t *, uint8_t *, const uint32_t *,
-                                      const uint32_t *, const Geometry &);
+                                      const uint32_t *, uint32_t, const Geometry &);
 
 template <typename T>
 void launch_lengths(hipStream_t s, const T *planes, const uint8_t *k_map, uint16_t *group_bits, uint32_t *tile_bits,

@@ -4,9 +4,11 @@
 // Encode is GPU-only by design: there is no CPU encode path in this library.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -44,7 +46,8 @@ struct Lane {
     uint64_t *h_sizes = nullptr;      // pinned: image_bytes[n] followed by image_off[n + 1]
     size_t h_sizes_cap = 0;
     DevBuf planes, counts, chain_len, chain_base, chain_prog, scalars, sorted_e, pix_of, k_map, block_state, group_bits,
-        tile_bits, tile_bitoff, image_bytes, image_off;
+        tile_bits, tile_bitoff, plane_sums, image_bytes, image_off, partial, block_tag;
+    uint32_t epoch = 0;               // sub-batches this lane has run: block tags are (epoch, slice)
     // the sub-batch in flight
     Geometry g;
     size_t first_image = 0;
@@ -56,7 +59,9 @@ struct Lane {
 struct felics_ctx {
     int device = -1;
     int max_lanes = MAX_LANES;  // FELICS_LANES=1..MAX_LANES overrides (tuning / per-kernel timing)
-    uint32_t epoch = 0;         // submission counter: block records are stamped (epoch, slice)
+    bool poison = false;        // FELICS_POISON=1: overwrite the workspace before every sub-batch (tests)
+    bool trace = false;         // FELICS_TRACE=1: synchronise and report after every stage (debugging)
+    int timeout_s = 120;        // FELICS_TIMEOUT_S: give up waiting for a submission after this long
     Lane lanes[MAX_LANES];
     std::string err;
     bool profiling = false;
@@ -78,6 +83,23 @@ int hip_fail(felics_ctx *ctx, hipError_t e, const char *what) {
         hipError_t e__ = (call);                                    \
         if (e__ != hipSuccess) return hip_fail(ctx, e__, #call);    \
     } while (0)
+
+// Wait for an event, but not forever: a kernel that does not return must surface as an error
+// (FELICS_E_HIP, "timed out"), not as a caller that hangs.
+int wait_event(felics_ctx *ctx, hipEvent_t ev, const char *what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; spins++) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return FELICS_OK;
+        if (e != hipErrorNotReady) return hip_fail(ctx, e, what);
+        if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if ((spins & 1023) == 1023 &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::seconds(ctx->timeout_s)) {
+            ctx->err = std::string(what) + ": timed out waiting for the GPU";
+            return FELICS_E_HIP;
+        }
+    }
+}
 
 int sync_all(felics_ctx *ctx) {
     for (Lane &l : ctx->lanes) {
@@ -102,6 +124,15 @@ int reserve(felics_ctx *ctx, DevBuf &b, size_t bytes) {
     return FELICS_OK;
 }
 
+// served[] is compared against an epoch: a fresh buffer must not match by accident
+int reserve_zeroed(felics_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return FELICS_OK;
+    int rc = reserve(ctx, b, bytes);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemset(b.p, 0, b.cap));
+    return FELICS_OK;
+}
+
 void release(DevBuf &b) {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
@@ -114,13 +145,17 @@ struct StageTimer {
     int st;
     hipStream_t stream;
     StageTimer(felics_ctx *c, Lane &l, int s, hipStream_t on) : ctx(c), lane(l), st(s), stream(on) {
-        if (ctx->profiling) {
+        if (ctx->profiling && !lane.ev_used[st]) {  // a stage launched slice by slice is timed first start to last stop
             (void)hipEventRecord(lane.ev[st][0], stream);
             lane.ev_used[st] = true;
         }
     }
     ~StageTimer() {
         if (ctx->profiling) (void)hipEventRecord(lane.ev[st][1], stream);
+        if (ctx->trace) {  // FELICS_TRACE: wait for the stage and say so (locating a kernel that does not return)
+            hipError_t e = hipStreamSynchronize(stream);
+            fprintf(stderr, "[felics] %s done (%s)\n", kStageNames[st], hipGetErrorString(e));
+        }
     }
 };
 
@@ -142,10 +177,18 @@ void header_bytes(uint8_t *o, uint32_t w, uint32_t h, int color, int depth) {
     }
 }
 
-// Stages up to the bit scan, queued on the lane's stream; the stream sizes are copied to the
-// lane's pinned buffer and `sized` is recorded behind them.
+// Everything one sub-batch needs, queued without waiting for the host:
+//   front stream : hist, offsets, scatter slice by slice
+//   spine stream : one spine launch behind every scatter slice
+//   tail stream  : behind every spine launch the k of the events it made servable, the code lengths
+//                  and bit offsets of that slice's tiles and -- when every stream has a fixed slot in
+//                  the output and a plane's offset in its stream is known up front (gray) -- the
+//                  packed bits of those tiles.  RGB packs after the last slice (the offset of planes
+//                  1 and 2 needs the size of the planes before them).
+// The stream sizes are copied to the lane's pinned buffer and `sized` is recorded behind them.
+// slot_stride == 0: no packing here (the caller places the streams exactly once it has the sizes).
 template <typename T, typename ET>
-int analyse(felics_ctx *ctx, Lane &l) {
+int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     const Geometry &g = l.g;
     const size_t nsamples = (size_t)g.nplanes * g.npix;
     const size_t slots = (size_t)max_event_slots(g);
@@ -159,9 +202,12 @@ int analyse(felics_ctx *ctx, Lane &l) {
     if ((rc = reserve(ctx, l.pix_of, slots * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.k_map, nsamples + STAGE_PAD)) != 0) return rc;
     if ((rc = reserve(ctx, l.block_state, (size_t)max_event_blocks(g) * 32)) != 0) return rc;
+    if ((rc = reserve(ctx, l.partial, (size_t)SLICES * g.nplanes * NCTX * 8)) != 0) return rc;
+    if ((rc = reserve_zeroed(ctx, l.block_tag, (size_t)max_event_blocks(g) * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.group_bits, (size_t)g.nplanes * g.pack_tiles * PACK_THREADS * 2)) != 0) return rc;
     if ((rc = reserve(ctx, l.tile_bits, (size_t)g.nplanes * g.pack_tiles * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.tile_bitoff, (size_t)g.nplanes * g.pack_tiles * 8)) != 0) return rc;
+    if ((rc = reserve(ctx, l.plane_sums, (size_t)g.nplanes * 16)) != 0) return rc;  // carry[nplanes], base[nplanes]
     if ((rc = reserve(ctx, l.image_bytes, (size_t)g.nimages * 8)) != 0) return rc;
     if ((rc = reserve(ctx, l.image_off, (size_t)(g.nimages + 1) * 8)) != 0) return rc;
     const size_t hs = (size_t)g.nimages * 2 + 1;
@@ -172,14 +218,29 @@ int analyse(felics_ctx *ctx, Lane &l) {
         l.h_sizes_cap = hs;
     }
 
-    hipStream_t s = l.stream, f = l.front;
+    hipStream_t s = l.stream, f = l.front, tl = l.tail;
+    if (getenv("FELICS_SERIAL")) f = tl = s;  // debugging aid: one stream, same order of launches
     const T *d_planes = (const T *)l.d_planes;
-    ctx->epoch++;
     auto *counts = (uint32_t *)l.counts.p;
     auto *chain_len = (uint32_t *)l.chain_len.p;
     auto *chain_base = (uint32_t *)l.chain_base.p;
     auto *chain_prog = (uint32_t *)l.chain_prog.p;
-    // front stream: classification, chain directory, then the events slice by slice
+    auto *plane_carry = (uint64_t *)l.plane_sums.p;
+    auto *plane_base = plane_carry + g.nplanes;
+    // tags of other sub-batches never match this epoch (the lane's tags are cleared when the counter wraps)
+    if (++l.epoch >= 0x0FFFFFFFu) {
+        HIP_TRY(ctx, hipMemset(l.block_tag.p, 0, l.block_tag.cap));
+        l.epoch = 1;
+    }
+    const uint32_t epoch = l.epoch;
+    const bool pack_by_slice = slot_stride != 0 && g.planes_per_image == 1;
+
+    // ---- front stream
+    if (ctx->poison) {  // FELICS_POISON: every intermediate buffer starts as garbage, as on a fresh context
+        DevBuf *bufs[] = {&l.counts, &l.chain_len, &l.chain_base, &l.sorted_e, &l.pix_of, &l.k_map, &l.block_state,
+                          &l.group_bits, &l.tile_bits, &l.tile_bitoff};
+        for (DevBuf *b : bufs) HIP_TRY(ctx, hipMemsetAsync(b->p, 0xA5, b->cap, f));
+    }
     {
         StageTimer t(ctx, l, ST_HIST, f);
         launch_hist<T>(f, d_planes, counts, g);
@@ -189,9 +250,13 @@ int analyse(felics_ctx *ctx, Lane &l) {
         launch_offsets(f, counts, chain_len, chain_base, (uint32_t *)l.scalars.p, g);
         launch_zero_padding<ET>(f, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, chain_base, chain_len, g);
         HIP_TRY(ctx, hipMemsetAsync(chain_prog, 0, (size_t)g.nplanes * NCTX * 32, f));
+        HIP_TRY(ctx, hipMemsetAsync(l.partial.p, 0, (size_t)SLICES * g.nplanes * NCTX * 8, f));
     }
-    uint32_t bounds[SLICES + 1];
-    for (int q = 0; q <= SLICES; q++) bounds[q] = (uint32_t)((uint64_t)g.sort_tiles * q / SLICES);
+    uint32_t bounds[SLICES + 1], pbounds[SLICES + 1];  // slice boundaries in sort tiles / pack tiles
+    for (int q = 0; q <= SLICES; q++) {
+        bounds[q] = (uint32_t)((uint64_t)g.sort_tiles * q / SLICES);
+        pbounds[q] = q == SLICES ? g.pack_tiles : std::min<uint32_t>(g.pack_tiles, bounds[q] * (SORT_TILE / PACK_TILE));
+    }
     {
         StageTimer t(ctx, l, ST_SCATTER, f);
         for (int q = 0; q < SLICES; q++) {
@@ -200,10 +265,7 @@ int analyse(felics_ctx *ctx, Lane &l) {
             HIP_TRY(ctx, hipEventRecord(l.slice_done[q], f));
         }
     }
-    // spine stream: follows the scatter slices, one launch per slice; tail stream: k of the events each
-    // spine launch made servable, while the spine moves on
-    hipStream_t tl = l.tail;
-    const uint32_t stamp0 = (ctx->epoch & 0x0FFFFFFFu) << 4;
+    // ---- spine stream
     HIP_TRY(ctx, hipStreamWaitEvent(s, l.slice_done[0], 0));
     {
         StageTimer t(ctx, l, ST_SPINE, s);
@@ -211,42 +273,63 @@ int analyse(felics_ctx *ctx, Lane &l) {
             if (q) HIP_TRY(ctx, hipStreamWaitEvent(s, l.slice_done[q], 0));
             if (bounds[q + 1] != bounds[q] || q + 1 == SLICES)
                 launch_spine<ET>(s, (const ET *)l.sorted_e.p, (uint32_t *)l.block_state.p, chain_base, chain_len, counts,
-                                 bounds[q + 1], chain_prog, stamp0 + (uint32_t)q + 1, g);
+                                 bounds[q + 1], chain_prog, (uint32_t *)l.block_tag.p, (uint32_t *)l.partial.p, epoch,
+                                 (uint32_t)q + 1, g);
             HIP_TRY(ctx, hipEventRecord(l.spine_done[q], s));
         }
     }
-    HIP_TRY(ctx, hipStreamWaitEvent(tl, l.spine_done[0], 0));
-    {
-        StageTimer t(ctx, l, ST_ASSIGN, tl);
-        for (int q = 0; q < SLICES; q++) {
-            if (q) HIP_TRY(ctx, hipStreamWaitEvent(tl, l.spine_done[q], 0));
-            if (bounds[q + 1] != bounds[q] || q + 1 == SLICES)
-                launch_assign<ET>(tl, (const ET *)l.sorted_e.p, (const uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
-                                  (const uint32_t *)l.block_state.p, (const uint32_t *)l.scalars.p,
-                                  stamp0 + (uint32_t)q + 1, g);
+    // ---- tail stream
+    HIP_TRY(ctx, hipMemsetAsync(plane_carry, 0, (size_t)g.nplanes * 16, tl));
+    for (int q = 0; q < SLICES; q++) {
+        HIP_TRY(ctx, hipStreamWaitEvent(tl, l.spine_done[q], 0));
+        const bool last = q + 1 == SLICES;
+        if (bounds[q + 1] == bounds[q] && !last) continue;
+        {
+            StageTimer t(ctx, l, ST_ASSIGN, tl);
+            launch_assign<ET>(tl, (const ET *)l.sorted_e.p, (const uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
+                              (const uint32_t *)l.block_state.p, (const uint32_t *)l.scalars.p,
+                              (const uint32_t *)l.block_tag.p, (const uint32_t *)l.partial.p, epoch, (uint32_t)q + 1, g);
+        }
+        {
+            StageTimer t(ctx, l, ST_LENGTHS, tl);
+            launch_lengths<T>(tl, d_planes, (const uint8_t *)l.k_map.p, (uint16_t *)l.group_bits.p,
+                              (uint32_t *)l.tile_bits.p, g, pbounds[q], pbounds[q + 1]);
+        }
+        {
+            StageTimer t(ctx, l, ST_BITSCAN, tl);
+            launch_bitscan_slice(tl, (const uint32_t *)l.tile_bits.p, (uint64_t *)l.tile_bitoff.p, plane_carry, g,
+                                 pbounds[q], pbounds[q + 1]);
+            if (last) launch_finish_sizes(tl, plane_carry, plane_base, (uint64_t *)l.image_bytes.p, g);
+        }
+        if (slot_stride != 0 && (pack_by_slice || last)) {
+            const uint32_t t0 = pack_by_slice ? pbounds[q] : 0, t1 = pbounds[q + 1];
+            {
+                StageTimer t(ctx, l, ST_ZERO, tl);
+                launch_zero_edges(tl, d_out, nullptr, slot_stride, (const uint64_t *)l.tile_bitoff.p,
+                                  (const uint32_t *)l.tile_bits.p, plane_base, g, t0, t1);
+            }
+            {
+                StageTimer t(ctx, l, ST_PACK, tl);
+                launch_pack<T>(tl, d_planes, (const uint8_t *)l.k_map.p, (const uint16_t *)l.group_bits.p,
+                               (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p, plane_base, nullptr,
+                               slot_stride, d_out, g, t0, t1);
+            }
         }
     }
-    s = tl;  // everything below runs on the tail stream
-    {
-        StageTimer t(ctx, l, ST_LENGTHS, s);
-        launch_lengths<T>(s, d_planes, (const uint8_t *)l.k_map.p, (uint16_t *)l.group_bits.p, (uint32_t *)l.tile_bits.p, g);
-    }
-    {
-        StageTimer t(ctx, l, ST_BITSCAN, s);
-        launch_bitscan(s, (const uint32_t *)l.tile_bits.p, (uint64_t *)l.tile_bitoff.p, (uint64_t *)l.image_bytes.p,
-                       (uint64_t *)l.image_off.p, g);
-    }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(l.h_sizes, l.image_bytes.p, (size_t)g.nimages * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipMemcpyAsync(l.h_sizes + g.nimages, l.image_off.p, (size_t)(g.nimages + 1) * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipEventRecord(l.sized, s));
+    HIP_TRY(ctx, hipMemcpyAsync(l.h_sizes, l.image_bytes.p, (size_t)g.nimages * 8, hipMemcpyDeviceToHost, tl));
+    HIP_TRY(ctx, hipEventRecord(l.sized, tl));
     return FELICS_OK;
 }
 
+// Exact placement: streams back to back at image_off (computed on the device from the sizes), every
+// byte of them zeroed, all tiles packed.  Used when the streams do not get fixed slots, and to redo a
+// sub-batch in which a stream outgrew its slot.
 template <typename T>
-int emit(felics_ctx *ctx, Lane &l, uint8_t *d_out) {
+int pack_exact(felics_ctx *ctx, Lane &l, uint8_t *d_out) {
     const Geometry &g = l.g;
     hipStream_t s = l.tail;
+    auto *plane_base = (uint64_t *)l.plane_sums.p + g.nplanes;
     {
         StageTimer t(ctx, l, ST_ZERO, s);
         launch_zero_streams(s, (uint32_t *)d_out, (const uint64_t *)l.image_off.p, g);
@@ -254,8 +337,8 @@ int emit(felics_ctx *ctx, Lane &l, uint8_t *d_out) {
     {
         StageTimer t(ctx, l, ST_PACK, s);
         launch_pack<T>(s, (const T *)l.d_planes, (const uint8_t *)l.k_map.p, (const uint16_t *)l.group_bits.p,
-                       (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p,
-                       (const uint64_t *)l.image_off.p, d_out, g);
+                       (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p, plane_base,
+                       (const uint64_t *)l.image_off.p, 0, d_out, g, 0, g.pack_tiles);
     }
     HIP_TRY(ctx, hipGetLastError());
     return FELICS_OK;
@@ -320,90 +403,114 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
 
     const size_t frame_bytes = (size_t)npix * planes;  // u8 samples
     const size_t per_pass = max_images_per_pass(npix, planes);
-    uint64_t out_base = 0;
-    size_t done = 0;
     int rc;
-    // Rounds of up to MAX_LANES sub-batches: analyse all of them (their spines overlap the other
-    // lanes' data-parallel kernels), then place and pack the streams in image order.
-    while (done < n) {
-        const size_t left = n - done;
-        const size_t nl = std::min<size_t>((size_t)ctx->max_lanes, std::max<size_t>(1, left / MIN_LANE_IMAGES));
-        // Later lanes get fewer images (weights nl, nl-1, .., 1): every lane pays the same spine
-        // latency, so the lane that starts last should have the least work left after its spine.
-        const size_t wsum = nl * (nl + 1) / 2;
-        size_t first = done;
-        int used = 0;
-        for (size_t li = 0; li < nl && first < n; li++) {
-            Lane &l = ctx->lanes[li];
-            size_t share = li + 1 == nl ? n - first : (left * (nl - li) + wsum - 1) / wsum;
-            const size_t cnt = std::min(std::min(per_pass, std::max<size_t>(1, share)), n - first);
-            Geometry &g = l.g;
-            g.W = w;
-            g.H = h;
-            g.npix = (uint32_t)npix;
-            g.nimages = (uint32_t)cnt;
-            g.planes_per_image = planes;
-            g.nplanes = (uint32_t)(cnt * planes);
-            g.sort_tiles = (uint32_t)((npix + SORT_TILE - 1) / SORT_TILE);
-            g.pack_tiles = (uint32_t)((npix + PACK_TILE - 1) / PACK_TILE);
-            g.color = (uint32_t)color;
-            g.depth = (uint32_t)depth;
-            l.first_image = first;
-            const uint8_t *src = (const uint8_t *)d_pixels + first * frame_bytes;
-            l.d_planes = src;
-            if (planes == 3) {
-                if ((rc = reserve(ctx, l.planes, (size_t)g.nplanes * npix * 2 + STAGE_PAD)) != 0) return rc;
-                StageTimer t(ctx, l, ST_PLANES, l.front);
-                launch_rgb8_to_planes(l.front, src, (int16_t *)l.planes.p, g.npix, g.nimages);
-                l.d_planes = l.planes.p;
-            }
-            rc = planes == 3 ? analyse<int16_t, uint16_t>(ctx, l) : analyse<uint8_t, uint8_t>(ctx, l);
-            if (rc) {
-                (void)sync_all(ctx);
-                return rc;
-            }
-            first += cnt;
-            used++;
-        }
-        // sizes of this round
-        uint64_t round_need = 0;
-        if (own_out) {  // the context's buffer may have to grow: wait for every size first
-            for (int li = 0; li < used; li++) {
-                HIP_TRY(ctx, hipEventSynchronize(ctx->lanes[li].sized));
-                round_need += ctx->lanes[li].h_sizes[(size_t)ctx->lanes[li].g.nimages * 2];
-            }
-            if (out_base != 0) return FELICS_E_UNSUPPORTED;  // host entry points submit one round at a time
-            if ((rc = reserve(ctx, ctx->out, round_need)) != 0) return rc;
-            d_out = (uint8_t *)ctx->out.p;
-            d_out_cap = ctx->out.cap;
-        }
-        bool too_small = false;
-        for (int li = 0; li < used; li++) {
-            Lane &l = ctx->lanes[li];
-            HIP_TRY(ctx, hipEventSynchronize(l.sized));
-            const size_t cnt = l.g.nimages;
-            const uint64_t need = l.h_sizes[cnt * 2];  // image_off[cnt]
-            if (!too_small && out_base + need <= d_out_cap) {
-                rc = planes == 3 ? emit<int16_t>(ctx, l, d_out + out_base) : emit<uint8_t>(ctx, l, d_out + out_base);
+    // Placement.  Preferred: every stream gets a fixed slot (stream i at i * slot), so packing needs no
+    // size from the host and follows the spine slice by slice.  If a stream outgrows its slot, or the
+    // caller's buffer is too small for sensible slots, the streams are placed back to back instead
+    // (exact sizes first, then one pack pass).
+    uint64_t slot = 0;
+    if (own_out) {
+        slot = ((uint64_t)frame_bytes + frame_bytes / 4 + 64 + 15) & ~15ull;
+        if ((rc = reserve(ctx, ctx->out, (size_t)(slot * n))) != 0) return rc;
+        d_out = (uint8_t *)ctx->out.p;
+        d_out_cap = ctx->out.cap;
+    } else {
+        slot = (d_out_cap / n) & ~15ull;
+        if (slot < 64 || slot < frame_bytes / 4) slot = 0;
+    }
+
+    for (int attempt = 0; attempt < 2; attempt++) {
+        size_t done = 0;
+        uint64_t out_base = 0;  // exact placement: where the next round's streams start
+        bool overflow = false;
+        // Rounds of up to max_lanes sub-batches (one round unless the batch is huge).
+        while (done < n && !overflow) {
+            const size_t left = n - done;
+            const size_t nl = std::min<size_t>((size_t)ctx->max_lanes, std::max<size_t>(1, left / MIN_LANE_IMAGES));
+            // Later lanes get fewer images (weights nl, nl-1, .., 1): every lane pays the same spine
+            // latency, so the lane that starts last should have the least work left after its spine.
+            const size_t wsum = nl * (nl + 1) / 2;
+            size_t first = done;
+            int used = 0;
+            for (size_t li = 0; li < nl && first < n; li++) {
+                Lane &l = ctx->lanes[li];
+                size_t share = li + 1 == nl ? n - first : (left * (nl - li) + wsum - 1) / wsum;
+                const size_t cnt = std::min(std::min(per_pass, std::max<size_t>(1, share)), n - first);
+                Geometry &g = l.g;
+                g.W = w;
+                g.H = h;
+                g.npix = (uint32_t)npix;
+                g.nimages = (uint32_t)cnt;
+                g.planes_per_image = planes;
+                g.nplanes = (uint32_t)(cnt * planes);
+                g.sort_tiles = (uint32_t)((npix + SORT_TILE - 1) / SORT_TILE);
+                g.pack_tiles = (uint32_t)((npix + PACK_TILE - 1) / PACK_TILE);
+                g.color = (uint32_t)color;
+                g.depth = (uint32_t)depth;
+                l.first_image = first;
+                const uint8_t *src = (const uint8_t *)d_pixels + first * frame_bytes;
+                l.d_planes = src;
+                if (planes == 3) {
+                    if ((rc = reserve(ctx, l.planes, (size_t)g.nplanes * npix * 2 + STAGE_PAD)) != 0) return rc;
+                    hipStream_t fs = getenv("FELICS_SERIAL") ? l.stream : l.front;
+                    StageTimer t(ctx, l, ST_PLANES, fs);
+                    launch_rgb8_to_planes(fs, src, (int16_t *)l.planes.p, g.npix, g.nimages);
+                    l.d_planes = l.planes.p;
+                }
+                uint8_t *lane_out = d_out + first * slot;
+                rc = planes == 3 ? run_lane<int16_t, uint16_t>(ctx, l, lane_out, slot)
+                                 : run_lane<uint8_t, uint8_t>(ctx, l, lane_out, slot);
                 if (rc) {
                     (void)sync_all(ctx);
                     return rc;
                 }
-            } else {
-                too_small = true;
+                first += cnt;
+                used++;
             }
-            for (size_t i = 0; i < cnt; i++) {
-                lens[l.first_image + i] = l.h_sizes[i];
-                offsets[l.first_image + i] = out_base + l.h_sizes[cnt + i];
+            for (int li = 0; li < used; li++) {
+                Lane &l = ctx->lanes[li];
+                if ((rc = wait_event(ctx, l.sized, "stream sizes")) != 0) return rc;
+                for (size_t i = 0; i < l.g.nimages; i++) {
+                    lens[l.first_image + i] = l.h_sizes[i];
+                    offsets[l.first_image + i] = (uint64_t)(l.first_image + i) * slot;
+                    if (slot != 0 && l.h_sizes[i] > slot) overflow = true;
+                }
             }
-            out_base += need;
+            if (slot == 0) {
+                // exact placement of this round: back to back, 16-byte aligned, in image order
+                uint64_t need = out_base;
+                for (size_t i = done; i < first; i++) {
+                    offsets[i] = need;
+                    need += (lens[i] + 15) & ~15ull;
+                }
+                if (own_out) {
+                    if (done != 0) return FELICS_E_UNSUPPORTED;  // the host entry points submit one round at a time
+                    if ((rc = reserve(ctx, ctx->out, (size_t)need)) != 0) return rc;  // waits for the device
+                    d_out = (uint8_t *)ctx->out.p;
+                    d_out_cap = ctx->out.cap;
+                }
+                if (need > d_out_cap) {
+                    (void)sync_all(ctx);
+                    lens[0] = need;  // capacity needed so far (a lower bound if more rounds would follow)
+                    return FELICS_E_BUFFER_TOO_SMALL;
+                }
+                for (int li = 0; li < used; li++) {
+                    Lane &l = ctx->lanes[li];
+                    launch_place_streams(l.tail, (const uint64_t *)l.image_bytes.p, (uint64_t *)l.image_off.p, l.g);
+                    uint8_t *lane_out = d_out + offsets[l.first_image];
+                    rc = planes == 3 ? pack_exact<int16_t>(ctx, l, lane_out) : pack_exact<uint8_t>(ctx, l, lane_out);
+                    if (rc) {
+                        (void)sync_all(ctx);
+                        return rc;
+                    }
+                }
+                out_base = need;
+            }
+            if ((rc = sync_all(ctx)) != 0) return rc;
+            done = first;
         }
-        if ((rc = sync_all(ctx)) != 0) return rc;
-        if (too_small) {
-            lens[0] = out_base;  // capacity needed so far (a lower bound if more rounds would follow)
-            return FELICS_E_BUFFER_TOO_SMALL;
-        }
-        done = first;
+        if (!overflow) break;
+        slot = 0;  // a stream outgrew its slot: do the batch again with exact placement
     }
     collect_timing(ctx);
     if (used_out) *used_out = d_out;
@@ -430,6 +537,9 @@ int felics_ctx_create(int device, felics_ctx **out) {
     // Four streams want four hardware queues of their own; ROCm's default is 4 per process and the
     // caller's stream takes one.  Only effective if the HIP runtime has not been initialised yet.
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    ctx->poison = getenv("FELICS_POISON") != nullptr;
+    ctx->trace = getenv("FELICS_TRACE") != nullptr;
+    if (const char *e = getenv("FELICS_TIMEOUT_S")) ctx->timeout_s = std::max(1, atoi(e));
     if (const char *e = getenv("FELICS_LANES")) {
         const int v = atoi(e);
         if (v >= 1 && v <= MAX_LANES) ctx->max_lanes = v;
@@ -463,7 +573,8 @@ void felics_ctx_destroy(felics_ctx *ctx) {
         if (l.stream) (void)hipStreamSynchronize(l.stream);
         if (l.tail) (void)hipStreamSynchronize(l.tail);
         DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map,
-                          &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.image_bytes, &l.image_off};
+                          &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.plane_sums, &l.image_bytes, &l.image_off,
+                          &l.partial, &l.block_tag};
         for (DevBuf *b : bufs) release(*b);
         if (l.h_sizes) (void)hipHostFree(l.h_sizes);
         for (int i = 0; i < ST_COUNT; i++)

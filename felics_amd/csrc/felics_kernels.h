@@ -63,28 +63,47 @@ template <typename ET>
 void launch_zero_padding(hipStream_t s, ET *sorted_e, uint32_t *pix_of, const uint32_t *chain_base,
                          const uint32_t *chain_len, const Geometry &g);
 
+// block_tag[b] = epoch << 4 | slice of the spine launch that resolved block b (4 bytes per 64-event block,
+// zero-initialised once; epoch in 1 .. 2^28 - 1, slice in 1..15).  partial = uint2[slices][chains]:
+// {block, events in place} of the chain's not-yet-full block after that slice (zeroed per sub-batch).
 template <typename ET>
 void launch_spine(hipStream_t s, const ET *sorted_e, uint32_t *block_state, const uint32_t *chain_base,
                   const uint32_t *chain_len, const uint32_t *tile_off, uint32_t t_end, uint32_t *chain_prog,
-                  uint32_t stamp, const Geometry &g);
+                  uint32_t *block_tag, uint32_t *partial, uint32_t epoch, uint32_t slice, const Geometry &g);
 
+// serves what the spine launch of `slice` published: the blocks it resolved and its partial blocks
 template <typename ET>
-// serves the blocks whose record carries `stamp` (written by the spine launch of the same slice)
 void launch_assign(hipStream_t s, const ET *sorted_e, const uint32_t *pix_of, uint8_t *k_map,
-                   const uint32_t *block_state, const uint32_t *total_slots, uint32_t stamp, const Geometry &g);
+                   const uint32_t *block_state, const uint32_t *total_slots, const uint32_t *block_tag,
+                   const uint32_t *partial, uint32_t epoch, uint32_t slice, const Geometry &g);
 
+// lengths / bit scan / pack work on a range [t0, t1) of every plane's PACK tiles, so they can follow the
+// spine slice by slice.  tile_bitoff is relative to the plane; plane_base (zero for gray, set by
+// launch_finish_sizes for the later planes of an RGB image) makes it relative to the image stream.
 template <typename T>
 void launch_lengths(hipStream_t s, const T *planes, const uint8_t *k_map, uint16_t *group_bits, uint32_t *tile_bits,
-                    const Geometry &g);
+                    const Geometry &g, uint32_t t0, uint32_t t1);
 
-void launch_bitscan(hipStream_t s, const uint32_t *tile_bits, uint64_t *tile_bitoff, uint64_t *image_bytes,
-                    uint64_t *image_off, const Geometry &g);
+void launch_bitscan_slice(hipStream_t s, const uint32_t *tile_bits, uint64_t *tile_bitoff, uint64_t *plane_carry,
+                          const Geometry &g, uint32_t t0, uint32_t t1);
 
+void launch_finish_sizes(hipStream_t s, const uint64_t *plane_carry, uint64_t *plane_base, uint64_t *image_bytes,
+                         const Geometry &g);
+
+// exact placement (streams back to back, 16-byte aligned) and zeroing of exactly those bytes
+void launch_place_streams(hipStream_t s, const uint64_t *image_bytes, uint64_t *image_off, const Geometry &g);
 void launch_zero_streams(hipStream_t s, uint32_t *out, const uint64_t *image_off, const Geometry &g);
+
+// Placement of the streams in `out`: slot_stride != 0 -> stream i at i * slot_stride (bytes), writes
+// beyond the slot are dropped; slot_stride == 0 -> stream i at image_off[i].
+void launch_zero_edges(hipStream_t s, uint8_t *out, const uint64_t *image_off, uint64_t slot_stride,
+                       const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint64_t *plane_base,
+                       const Geometry &g, uint32_t t0, uint32_t t1);
 
 template <typename T>
 void launch_pack(hipStream_t s, const T *planes, const uint8_t *k_map, const uint16_t *group_bits,
-                 const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint64_t *image_off, uint8_t *out,
-                 const Geometry &g);
+                 const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint64_t *plane_base,
+                 const uint64_t *image_off, uint64_t slot_stride, uint8_t *out, const Geometry &g, uint32_t t0,
+                 uint32_t t1);
 
 }  // namespace felics

@@ -383,7 +383,8 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
                                               const uint32_t *__restrict__ chain_base,
                                               const uint32_t *__restrict__ chain_len, uint32_t nchains,
                                               const uint32_t *__restrict__ tile_off, uint32_t ntiles, uint32_t t_end,
-                                              uint32_t *__restrict__ chain_prog, uint32_t stamp) {
+                                              uint32_t *__restrict__ chain_prog, uint32_t *__restrict__ block_tag,
+                                              uint2 *__restrict__ partial, uint32_t stamp) {
     constexpr uint32_t DW = 64 * sizeof(ET) / 4;  // dwords per block
     __shared__ uint32_t stage[SPINE_BATCH * DW];          // the batch's events
     __shared__ uint32_t bsum[(SPINE_BATCH + 1) * 8];      // [block][k]: sum of the block's lengths for k = 0..5
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
     const uint32_t base = chain_base[chain];  // multiple of 64
     const uint4 *src = reinterpret_cast<const uint4 *>(sorted_e + base);  // block b = DW/4 uint4 at b*DW/4
     uint4 *states = reinterpret_cast<uint4 *>(block_state) + (uint64_t)(base >> 6) * 2;
+    uint32_t *tags = block_tag + (base >> 6);  // per block: (epoch, slice) of the launch that resolved it
     uint32_t Sv = l7 < 6 ? prog[1 + l7] : 0u;
     if (first_block < nblocks) {
     __builtin_amdgcn_s_setprio(3);  // a chain is one long dependent instruction stream: never make it wait for issue
@@ -489,90 +491,110 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
         if (lane < nb) {
             const uint4 hi = reinterpret_cast<const uint4 *>(rec)[lane * 2 + 1];
             states[(uint64_t)(bb + lane) * 2] = reinterpret_cast<const uint4 *>(rec)[lane * 2];
-            states[(uint64_t)(bb + lane) * 2 + 1] = make_uint4(hi.x, hi.y, stamp, 64u);  // a whole block, resolved in this launch
+            states[(uint64_t)(bb + lane) * 2 + 1] = make_uint4(hi.x, hi.y, 0u, 0u);
+            tags[bb + lane] = stamp;  // resolved in this launch (a block is resolved exactly once)
         }
         __syncthreads();
     }
     if (lane < 6) prog[1 + lane] = Sv;
     if (lane == 6) prog[0] = nblocks;
     }
-    // Events that are in place but do not fill a block yet: publish the block's start state and how many
-    // of its events exist, so k_assign can serve them now (the block is resolved by a later launch).
+    // Events that are in place but do not fill a block yet: publish the block's start state and, in this
+    // launch's own list (never overwritten by a later launch), which block it is and how many of its
+    // events exist, so k_assign can serve them now.  The block itself is resolved by a later launch.
     if (!final_slice && (avail & 63u) != 0) {
         const uint32_t s0 = readlane(Sv, 0), s1 = readlane(Sv, 1), s2 = readlane(Sv, 2);
         const uint32_t s3 = readlane(Sv, 3), s4 = readlane(Sv, 4), s5 = readlane(Sv, 5);
         if (lane == 0) {
             states[(uint64_t)nblocks * 2] = make_uint4(s0, s1, s2, s3);
-            states[(uint64_t)nblocks * 2 + 1] = make_uint4(s4, s5, stamp, avail & 63u);
+            states[(uint64_t)nblocks * 2 + 1] = make_uint4(s4, s5, 0u, 0u);
+            partial[chain] = make_uint2((base >> 6) + nblocks, avail & 63u);
         }
     }
 }
 
-// One wave per 64-event block (chains are 64-aligned, so a block never straddles two chains):
-// start state from k_spine, the block's in-wave prefix sums, k for every event, stored at the
-// event's pixel (k_map is in raster order, one byte per sample; only event pixels are written).
+// k of every event.  A block's record (k_spine) holds the estimator state at its first event; a wave
+// redoes the block's in-wave prefix sums and halvings and stores k at each event's pixel (k_map is in
+// raster order, one byte per sample; only event pixels are written).
+//
+// The kernel runs once per slice, right behind that slice's spine launch, and serves exactly what
+// that launch published: the blocks it resolved (block_tag == this epoch and slice) and, per chain, the
+// one block that has events in place but is not full yet (partial[chain] = {block, events}).  Later spine
+// launches may already be running: they tag other blocks and rewrite a partial block's record with the
+// same values, so nothing read here is in flux.  Waves scan 64 tags / 64 list entries at a time.
+constexpr uint32_t TAG_SLICE_BITS = 4;  // tag = epoch << 4 | slice
+
+__device__ __forceinline__ void assign_block(const uint4 *__restrict__ st, const uint32_t gb, const uint32_t valid,
+                                             const uint32_t e, const uint32_t pix, uint8_t *__restrict__ k_map) {
+    const uint32_t lane = lane_id();
+    const uint4 sa = st[(uint64_t)gb * 2], sb = st[(uint64_t)gb * 2 + 1];
+    uint32_t S0 = sa.x, S1 = sa.y, S2 = sa.z, S3 = sa.w, S4 = sb.x, S5 = sb.y;
+    uint32_t l01, l23, l45;
+    packed_lengths(e, l01, l23, l45);
+    const uint32_t p01 = wave_incl_scan(l01), p23 = wave_incl_scan(l23), p45 = wave_incl_scan(l45);
+    const uint32_t P0 = p01 & 0xFFFFu, P1 = p01 >> 16, P2 = p23 & 0xFFFFu, P3 = p23 >> 16;
+    const uint32_t P4 = p45 & 0xFFFFu, P5 = p45 >> 16;
+    const uint32_t l0 = l01 & 0xFFFFu, l1 = l01 >> 16, l2 = l23 & 0xFFFFu, l3 = l23 >> 16, l4 = l45 & 0xFFFFu,
+                   l5 = l45 >> 16;
+    uint32_t kk = 0, lo = 0;
+    while (true) {
+        const uint32_t T0 = S0 + P0, T1 = S1 + P1, T2 = S2 + P2, T3 = S3 + P3, T4 = S4 + P4, T5 = S5 + P5;
+        const uint32_t mn = min(min(min(T0, T1), min(T2, T3)), min(T4, T5));
+        // state BEFORE this lane's event -> its k (get_k precedes update, compression.rs:127,139)
+        const uint32_t X0 = T0 - l0, X1 = T1 - l1, X2 = T2 - l2, X3 = T3 - l3, X4 = T4 - l4, X5 = T5 - l5;
+        const uint32_t key = min(min(min((X0 << 3) | 7u, (X1 << 3) | 6u), min((X2 << 3) | 5u, (X3 << 3) | 4u)),
+                                 min((X4 << 3) | 3u, (X5 << 3) | 2u));
+        const uint32_t cand = 7u - (key & 7u);
+        const uint64_t hm = __ballot(lane >= lo && mn > 1024u);
+        if (hm == 0) {
+            if (lane >= lo) kk = cand;
+            break;
+        }
+        const uint32_t f = (uint32_t)__ffsll((long long)hm) - 1u;
+        if (lane >= lo && lane <= f) kk = cand;
+        const uint32_t f0 = readlane(P0, f), f1 = readlane(P1, f), f2 = readlane(P2, f);
+        const uint32_t f3 = readlane(P3, f), f4 = readlane(P4, f), f5 = readlane(P5, f);
+        S0 = ((S0 + f0) >> 1) - f0; S1 = ((S1 + f1) >> 1) - f1; S2 = ((S2 + f2) >> 1) - f2;
+        S3 = ((S3 + f3) >> 1) - f3; S4 = ((S4 + f4) >> 1) - f4; S5 = ((S5 + f5) >> 1) - f5;
+        lo = f + 1;
+        if (lo >= 64) break;
+    }
+    // lanes past the block's events in place hold no event yet; padding slots belong to no pixel
+    if (lane < valid && pix != 0xFFFFFFFFu) k_map[pix] = (uint8_t)kk;
+}
+
 template <typename ET>
 __global__ __launch_bounds__(256) void k_assign(const ET *__restrict__ sorted_e, const uint32_t *__restrict__ block_state,
                                                 const uint32_t *__restrict__ pix_of, uint8_t *__restrict__ k_map,
-                                                const uint32_t *__restrict__ total_slots, uint32_t stamp) {
+                                                const uint32_t *__restrict__ total_slots,
+                                                const uint32_t *__restrict__ block_tag,
+                                                const uint2 *__restrict__ partial, uint32_t nchains, uint32_t stamp) {
     const uint32_t lane = lane_id();
     const uint32_t nblocks = *total_slots >> 6;
     const uint32_t nwaves = gridDim.x * 4;
-    uint32_t gb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (gb >= nblocks) return;
-    // Grid-stride over the blocks.  Only blocks whose record carries this launch's stamp are served
-    // (written by the spine launch of the same slice); the next record is requested ahead, a block's
-    // events and pixels are only fetched when it is served.  Record: {S0..S3}, {S4, S5, stamp, valid events}.
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint4 *st = reinterpret_cast<const uint4 *>(block_state);
-    uint4 sa = st[(uint64_t)gb * 2], sb = st[(uint64_t)gb * 2 + 1];
-    while (true) {
-        const uint32_t nxt = gb + nwaves;
-        const bool more = nxt < nblocks;
-        uint4 na = sa, nbv = sb;
-        if (more) {
-            na = st[(uint64_t)nxt * 2];
-            nbv = st[(uint64_t)nxt * 2 + 1];
+    // blocks resolved by this slice's spine launch
+    for (uint32_t g0 = wave * 64; g0 < nblocks; g0 += nwaves * 64) {
+        const uint32_t mine = g0 + lane;
+        uint64_t todo = __ballot(mine < nblocks && block_tag[mine] == stamp);
+        while (todo) {
+            const uint32_t gb = g0 + (uint32_t)__ffsll((long long)todo) - 1u;
+            todo &= todo - 1;
+            assign_block(st, gb, 64u, (uint32_t)sorted_e[(uint64_t)gb * 64 + lane], pix_of[(uint64_t)gb * 64 + lane], k_map);
         }
-        if (sb.z == stamp) {
-        const uint32_t e = (uint32_t)sorted_e[(uint64_t)gb * 64 + lane];
-        const uint32_t pix = pix_of[(uint64_t)gb * 64 + lane];
-        uint32_t S0 = sa.x, S1 = sa.y, S2 = sa.z, S3 = sa.w, S4 = sb.x, S5 = sb.y;
-        uint32_t l01, l23, l45;
-        packed_lengths(e, l01, l23, l45);
-        const uint32_t p01 = wave_incl_scan(l01), p23 = wave_incl_scan(l23), p45 = wave_incl_scan(l45);
-        const uint32_t P0 = p01 & 0xFFFFu, P1 = p01 >> 16, P2 = p23 & 0xFFFFu, P3 = p23 >> 16;
-        const uint32_t P4 = p45 & 0xFFFFu, P5 = p45 >> 16;
-        const uint32_t l0 = l01 & 0xFFFFu, l1 = l01 >> 16, l2 = l23 & 0xFFFFu, l3 = l23 >> 16, l4 = l45 & 0xFFFFu,
-                       l5 = l45 >> 16;
-        uint32_t kk = 0, lo = 0;
-        while (true) {
-            const uint32_t T0 = S0 + P0, T1 = S1 + P1, T2 = S2 + P2, T3 = S3 + P3, T4 = S4 + P4, T5 = S5 + P5;
-            const uint32_t mn = min(min(min(T0, T1), min(T2, T3)), min(T4, T5));
-            // state BEFORE this lane's event -> its k (get_k precedes update, compression.rs:127,139)
-            const uint32_t X0 = T0 - l0, X1 = T1 - l1, X2 = T2 - l2, X3 = T3 - l3, X4 = T4 - l4, X5 = T5 - l5;
-            const uint32_t key = min(min(min((X0 << 3) | 7u, (X1 << 3) | 6u), min((X2 << 3) | 5u, (X3 << 3) | 4u)),
-                                     min((X4 << 3) | 3u, (X5 << 3) | 2u));
-            const uint32_t cand = 7u - (key & 7u);
-            const uint64_t hm = __ballot(lane >= lo && mn > 1024u);
-            if (hm == 0) {
-                if (lane >= lo) kk = cand;
-                break;
-            }
-            const uint32_t f = (uint32_t)__ffsll((long long)hm) - 1u;
-            if (lane >= lo && lane <= f) kk = cand;
-            const uint32_t f0 = readlane(P0, f), f1 = readlane(P1, f), f2 = readlane(P2, f);
-            const uint32_t f3 = readlane(P3, f), f4 = readlane(P4, f), f5 = readlane(P5, f);
-            S0 = ((S0 + f0) >> 1) - f0; S1 = ((S1 + f1) >> 1) - f1; S2 = ((S2 + f2) >> 1) - f2;
-            S3 = ((S3 + f3) >> 1) - f3; S4 = ((S4 + f4) >> 1) - f4; S5 = ((S5 + f5) >> 1) - f5;
-            lo = f + 1;
-            if (lo >= 64) break;
+    }
+    // per chain: the block with events in place that is not full yet
+    for (uint32_t c0 = wave * 64; c0 < nchains; c0 += nwaves * 64) {
+        uint2 entry = make_uint2(0u, 0u);
+        if (c0 + lane < nchains) entry = partial[c0 + lane];
+        uint64_t todo = __ballot(entry.y != 0);
+        while (todo) {
+            const uint32_t b = (uint32_t)__ffsll((long long)todo) - 1u;
+            todo &= todo - 1;
+            const uint32_t gb = readlane(entry.x, b), valid = readlane(entry.y, b);
+            assign_block(st, gb, valid, (uint32_t)sorted_e[(uint64_t)gb * 64 + lane], pix_of[(uint64_t)gb * 64 + lane], k_map);
         }
-        if (lane < sb.w && pix != 0xFFFFFFFFu) k_map[pix] = (uint8_t)kk;
-        }
-        if (!more) break;
-        gb = nxt;
-        sa = na;
-        sb = nbv;
     }
 }
 
@@ -749,10 +771,11 @@ template <typename T>
 __global__ __launch_bounds__(PACK_THREADS) void k_lengths(const T *__restrict__ planes, const uint8_t *__restrict__ k_map,
                                                           uint16_t *__restrict__ group_bits,
                                                           uint32_t *__restrict__ tile_bits, uint32_t W, uint32_t npix,
-                                                          uint32_t ntiles, uint32_t planes_per_image) {
+                                                          uint32_t ntiles, uint32_t planes_per_image,
+                                                          uint32_t tile_begin) {
     __shared__ TileLDS<T> tl;
     __shared__ uint32_t wsum[PACK_THREADS / 64];
-    const uint32_t tile = blockIdx.x, plane = blockIdx.y;
+    const uint32_t tile = tile_begin + blockIdx.x, plane = blockIdx.y;
     const T *pl = planes + (uint64_t)plane * npix;
     const uint32_t tile_first = tile * PACK_TILE;
     stage_tile(tl, pl, k_map + (uint64_t)plane * npix, tile_first, W, npix);
@@ -776,24 +799,27 @@ __global__ __launch_bounds__(PACK_THREADS) void k_lengths(const T *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// bitscan: one block per image; exclusive scan of its planes' tile bits (planes are
-// concatenated with no alignment, compression.rs:365-367).  Also the stream's byte size.
+// bitscan: bit offset of every tile inside its plane, slice by slice.  One block per plane scans the
+// tiles [t0, t1) of its plane on top of the plane's running total (plane_carry).  When the last slice
+// is done k_finish_sizes turns the plane totals into each plane's offset inside its image stream
+// (planes are concatenated with no alignment, compression.rs:365-367) and the stream's byte size.
 // ------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(1024) void k_bitscan(const uint32_t *__restrict__ tile_bits,
-                                                  uint64_t *__restrict__ tile_bitoff,
-                                                  uint64_t *__restrict__ image_bytes, uint32_t tiles_per_image) {
+__global__ __launch_bounds__(1024) void k_bitscan_slice(const uint32_t *__restrict__ tile_bits,
+                                                        uint64_t *__restrict__ tile_bitoff,
+                                                        uint64_t *__restrict__ plane_carry, uint32_t ntiles,
+                                                        uint32_t t0, uint32_t t1) {
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t carry;
-    const uint32_t img = blockIdx.x;
+    const uint32_t plane = blockIdx.x;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    const uint32_t *src = tile_bits + (uint64_t)img * tiles_per_image;
-    uint64_t *dst = tile_bitoff + (uint64_t)img * tiles_per_image;
-    if (threadIdx.x == 0) carry = 0;
+    const uint32_t *src = tile_bits + (uint64_t)plane * ntiles;
+    uint64_t *dst = tile_bitoff + (uint64_t)plane * ntiles;
+    if (threadIdx.x == 0) carry = plane_carry[plane];
     __syncthreads();
-    for (uint32_t base = 0; base < tiles_per_image; base += 1024) {
+    for (uint32_t base = t0; base < t1; base += 1024) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < tiles_per_image ? src[i] : 0;
+        const uint32_t v = i < t1 ? src[i] : 0;
         // tile totals are < 2^32 but a wave of them may not be: scan low/high halves apart
         const uint32_t lo = wave_incl_scan(v & 0xFFFFu), hi = wave_incl_scan(v >> 16);
         const uint64_t inc = (uint64_t)lo + ((uint64_t)hi << 16);
@@ -802,12 +828,56 @@ __global__ __launch_bounds__(1024) void k_bitscan(const uint32_t *__restrict__ t
         uint64_t woff = 0;
         for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
         const uint64_t c = carry;
-        if (i < tiles_per_image) dst[i] = c + woff + inc - v;
+        if (i < t1) dst[i] = c + woff + inc - v;
         __syncthreads();
         if (threadIdx.x == 1023) carry = c + woff + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0) image_bytes[img] = (carry + 7) >> 3;  // byte_align (compression.rs:279)
+    if (threadIdx.x == 0) plane_carry[plane] = carry;
+}
+
+__global__ void k_finish_sizes(const uint64_t *__restrict__ plane_carry, uint64_t *__restrict__ plane_base,
+                               uint64_t *__restrict__ image_bytes, uint32_t nimages, uint32_t planes_per_image) {
+    const uint32_t img = blockIdx.x * blockDim.x + threadIdx.x;
+    if (img >= nimages) return;
+    uint64_t bits = 0;
+    for (uint32_t c = 0; c < planes_per_image; c++) {
+        plane_base[img * planes_per_image + c] = bits;
+        bits += plane_carry[img * planes_per_image + c];
+    }
+    image_bytes[img] = (bits + 7) >> 3;  // byte_align (compression.rs:279)
+}
+
+// Where a tile's bits live: stream base (fixed slot per image, or exact placement) and bit range.
+struct Placement {
+    const uint64_t *image_off;  // exact placement (slot_stride == 0): byte offset of every stream
+    uint64_t slot_stride;       // fixed slots: stream i starts at i * slot_stride bytes
+};
+
+__device__ __forceinline__ uint32_t *stream_words(uint8_t *out, const Placement &pl, uint32_t img, uint64_t &limit_words) {
+    if (pl.slot_stride) {
+        limit_words = pl.slot_stride >> 2;
+        return reinterpret_cast<uint32_t *>(out + (uint64_t)img * pl.slot_stride);
+    }
+    limit_words = ~0ull;
+    return reinterpret_cast<uint32_t *>(out + pl.image_off[img]);
+}
+
+// pack ORs a tile's last word (and its first word when the previous tile ends inside it) into the
+// output: zero the last word of every tile of the range.  A tile that lies inside one word shared
+// with its predecessor leaves that word alone (the predecessor zeroed it, and may already have packed).
+__global__ void k_zero_edges(uint8_t *__restrict__ out, Placement place, const uint64_t *__restrict__ tile_bitoff,
+                             const uint32_t *__restrict__ tile_bits, const uint64_t *__restrict__ plane_base,
+                             uint32_t ntiles, uint32_t t0, uint32_t t1, uint32_t planes_per_image) {
+    const uint32_t tile = t0 + blockIdx.x * blockDim.x + threadIdx.x, plane = blockIdx.y;
+    if (tile >= t1) return;
+    const uint64_t lo = plane_base[plane] + tile_bitoff[(uint64_t)plane * ntiles + tile];
+    const uint64_t hi = lo + tile_bits[(uint64_t)plane * ntiles + tile];
+    const uint64_t first_word = lo >> 5, last_word = (hi - 1) >> 5;
+    if (first_word == last_word && (lo & 31u) != 0) return;
+    uint64_t limit;
+    uint32_t *words = stream_words(out, place, plane / planes_per_image, limit);
+    if (last_word < limit) words[last_word] = 0;
 }
 
 // Stream placement: offsets[i] = sum of 16-byte-rounded sizes before i; one thread (n is small).
@@ -907,14 +977,14 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ pla
                                                        const uint16_t *__restrict__ group_bits,
                                                        const uint64_t *__restrict__ tile_bitoff,
                                                        const uint32_t *__restrict__ tile_bits,
-                                                       const uint64_t *__restrict__ image_off,
+                                                       const uint64_t *__restrict__ plane_base, Placement place,
                                                        uint8_t *__restrict__ out, uint32_t W, uint32_t H,
                                                        uint32_t npix, uint32_t ntiles, uint32_t planes_per_image,
-                                                       uint32_t color, uint32_t depth) {
+                                                       uint32_t color, uint32_t depth, uint32_t tile_begin) {
     __shared__ TileLDS<T> tl;
     __shared__ uint32_t win[PACK_WIN_WORDS];
     __shared__ uint32_t wsum[PACK_THREADS / 64];
-    const uint32_t tile = blockIdx.x, plane = blockIdx.y;
+    const uint32_t tile = tile_begin + blockIdx.x, plane = blockIdx.y;
     const uint32_t img = plane / planes_per_image;
     const bool first_plane = (plane % planes_per_image) == 0;
     const T *pl = planes + (uint64_t)plane * npix;
@@ -931,12 +1001,14 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ pla
     __syncthreads();
     uint32_t woff = 0;
     for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) woff += wsum[w];
-    const uint64_t tile_lo = tile_bitoff[(uint64_t)plane * ntiles + tile];  // bit offset in the image stream
+    const uint64_t tile_lo = plane_base[plane] + tile_bitoff[(uint64_t)plane * ntiles + tile];  // bit offset in the image stream
     const uint64_t tile_hi = tile_lo + tile_bits[(uint64_t)plane * ntiles + tile];
     const uint64_t my_lo = tile_lo + woff + inc - bits;
 
-    uint32_t *out_words = reinterpret_cast<uint32_t *>(out + image_off[img]);
+    uint64_t limit_words;  // a stream that outgrows its slot is cut here (the host then re-packs with exact placement)
+    uint32_t *out_words = stream_words(out, place, img, limit_words);
     const uint64_t first_word = tile_lo >> 5, last_word = (tile_hi - 1) >> 5;
+    const bool first_shared = (tile_lo & 31u) != 0;  // the previous tile ends inside our first word
 
     for (uint64_t w0 = first_word; w0 <= last_word; w0 += PACK_WIN_WORDS) {
         for (uint32_t j = threadIdx.x; j < PACK_WIN_WORDS; j += PACK_THREADS) win[j] = 0;
@@ -964,10 +1036,10 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ pla
         __syncthreads();
         for (uint32_t j = threadIdx.x; j < PACK_WIN_WORDS; j += PACK_THREADS) {
             const uint64_t aw = w0 + j;
-            if (aw > last_word) break;
+            if (aw > last_word || aw >= limit_words) break;
             const uint32_t v = __builtin_bswap32(win[j]);
-            if (aw == first_word || aw == last_word) {
-                if (v) atomicOr(&out_words[aw], v);
+            if ((aw == first_word && first_shared) || aw == last_word) {
+                if (v) atomicOr(&out_words[aw], v);  // zeroed beforehand (k_zero_edges / k_zero_streams)
             } else {
                 out_words[aw] = v;
             }
@@ -1032,45 +1104,65 @@ template void launch_zero_padding<uint16_t>(hipStream_t, uint16_t *, uint32_t *,
 template <typename ET>
 void launch_spine(hipStream_t s, const ET *sorted_e, uint32_t *block_state, const uint32_t *chain_base,
                   const uint32_t *chain_len, const uint32_t *tile_off, uint32_t t_end, uint32_t *chain_prog,
-                  uint32_t stamp, const Geometry &g) {
+                  uint32_t *block_tag, uint32_t *partial, uint32_t epoch, uint32_t slice, const Geometry &g) {
     const uint32_t nchains = g.nplanes * NCTX;
     hipLaunchKernelGGL((k_spine<ET>), dim3(nchains), dim3(64), 0, s, sorted_e, block_state, chain_base, chain_len,
-                       nchains, tile_off, g.sort_tiles, t_end, chain_prog, stamp);
+                       nchains, tile_off, g.sort_tiles, t_end, chain_prog, block_tag,
+                       reinterpret_cast<uint2 *>(partial) + (uint64_t)(slice - 1) * nchains,
+                       (epoch << TAG_SLICE_BITS) | slice);
 }
 template void launch_spine<uint8_t>(hipStream_t, const uint8_t *, uint32_t *, const uint32_t *, const uint32_t *,
-                                    const uint32_t *, uint32_t, uint32_t *, uint32_t, const Geometry &);
+                                    const uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t,
+                                    const Geometry &);
 template void launch_spine<uint16_t>(hipStream_t, const uint16_t *, uint32_t *, const uint32_t *, const uint32_t *,
-                                     const uint32_t *, uint32_t, uint32_t *, uint32_t, const Geometry &);
+                                     const uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t,
+                                     const Geometry &);
 
 template <typename ET>
 void launch_assign(hipStream_t s, const ET *sorted_e, const uint32_t *pix_of, uint8_t *k_map,
-                   const uint32_t *block_state, const uint32_t *total_slots, uint32_t stamp, const Geometry &g) {
-    // persistent: 8 workgroups of 4 waves per CU walk all blocks (fewer if there cannot be that many blocks)
+                   const uint32_t *block_state, const uint32_t *total_slots, const uint32_t *block_tag,
+                   const uint32_t *partial, uint32_t epoch, uint32_t slice, const Geometry &g) {
+    // persistent: 8 workgroups of 4 waves per CU walk all tags (fewer if there cannot be that many blocks)
+    const uint32_t nchains = g.nplanes * NCTX;
     const uint32_t max_blocks = max_event_blocks(g);
-    const uint32_t wgs = std::min<uint32_t>(cdiv(max_blocks, 4), 256u * 8u);
+    const uint32_t wgs = std::min<uint32_t>(cdiv(max_blocks, 4 * 64), 256u * 8u);
     hipLaunchKernelGGL((k_assign<ET>), dim3(wgs), dim3(256), 0, s, sorted_e, block_state, pix_of, k_map, total_slots,
-                       stamp);
+                       block_tag, reinterpret_cast<const uint2 *>(partial) + (uint64_t)(slice - 1) * nchains, nchains,
+                       (epoch << TAG_SLICE_BITS) | slice);
 }
 template void launch_assign<uint8_t>(hipStream_t, const uint8_t *, const uint32_t *, uint8_t *, const uint32_t *,
-                                     const uint32_t *, uint32_t, const Geometry &);
+                                     const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, uint32_t,
+                                     const Geometry &);
 template void launch_assign<uint16_t>(hipStream_t, const uint16_t *, const uint32_t *, uint8_t *, const uint32_t *,
-                                      const uint32_t *, uint32_t, const Geometry &);
+                                      const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, uint32_t,
+                                      const Geometry &);
 
 template <typename T>
 void launch_lengths(hipStream_t s, const T *planes, const uint8_t *k_map, uint16_t *group_bits, uint32_t *tile_bits,
-                    const Geometry &g) {
-    hipLaunchKernelGGL((k_lengths<T>), dim3(g.pack_tiles, g.nplanes), dim3(PACK_THREADS), 0, s, planes, k_map,
-                       group_bits, tile_bits, g.W, g.npix, g.pack_tiles, g.planes_per_image);
+                    const Geometry &g, uint32_t t0, uint32_t t1) {
+    if (t1 <= t0) return;
+    hipLaunchKernelGGL((k_lengths<T>), dim3(t1 - t0, g.nplanes), dim3(PACK_THREADS), 0, s, planes, k_map, group_bits,
+                       tile_bits, g.W, g.npix, g.pack_tiles, g.planes_per_image, t0);
 }
 template void launch_lengths<uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, uint16_t *, uint32_t *,
-                                      const Geometry &);
+                                      const Geometry &, uint32_t, uint32_t);
 template void launch_lengths<int16_t>(hipStream_t, const int16_t *, const uint8_t *, uint16_t *, uint32_t *,
-                                      const Geometry &);
+                                      const Geometry &, uint32_t, uint32_t);
 
-void launch_bitscan(hipStream_t s, const uint32_t *tile_bits, uint64_t *tile_bitoff, uint64_t *image_bytes,
-                    uint64_t *image_off, const Geometry &g) {
-    hipLaunchKernelGGL(k_bitscan, dim3(g.nimages), dim3(1024), 0, s, tile_bits, tile_bitoff, image_bytes,
-                       g.pack_tiles * g.planes_per_image);
+void launch_bitscan_slice(hipStream_t s, const uint32_t *tile_bits, uint64_t *tile_bitoff, uint64_t *plane_carry,
+                          const Geometry &g, uint32_t t0, uint32_t t1) {
+    if (t1 <= t0) return;
+    hipLaunchKernelGGL(k_bitscan_slice, dim3(g.nplanes), dim3(1024), 0, s, tile_bits, tile_bitoff, plane_carry,
+                       g.pack_tiles, t0, t1);
+}
+
+void launch_finish_sizes(hipStream_t s, const uint64_t *plane_carry, uint64_t *plane_base, uint64_t *image_bytes,
+                         const Geometry &g) {
+    hipLaunchKernelGGL(k_finish_sizes, dim3(cdiv(g.nimages, 64)), dim3(64), 0, s, plane_carry, plane_base, image_bytes,
+                       g.nimages, g.planes_per_image);
+}
+
+void launch_place_streams(hipStream_t s, const uint64_t *image_bytes, uint64_t *image_off, const Geometry &g) {
     hipLaunchKernelGGL(k_place_streams, dim3(1), dim3(64), 0, s, image_bytes, image_off, g.nimages);
 }
 
@@ -1078,17 +1170,31 @@ void launch_zero_streams(hipStream_t s, uint32_t *out, const uint64_t *image_off
     hipLaunchKernelGGL(k_zero_streams, dim3(256 * 8), dim3(256), 0, s, out, image_off, g.nimages);
 }
 
+void launch_zero_edges(hipStream_t s, uint8_t *out, const uint64_t *image_off, uint64_t slot_stride,
+                       const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint64_t *plane_base,
+                       const Geometry &g, uint32_t t0, uint32_t t1) {
+    if (t1 <= t0) return;
+    Placement pl{image_off, slot_stride};
+    hipLaunchKernelGGL(k_zero_edges, dim3(cdiv(t1 - t0, 256), g.nplanes), dim3(256), 0, s, out, pl, tile_bitoff, tile_bits,
+                       plane_base, g.pack_tiles, t0, t1, g.planes_per_image);
+}
+
 template <typename T>
 void launch_pack(hipStream_t s, const T *planes, const uint8_t *k_map, const uint16_t *group_bits,
-                 const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint64_t *image_off, uint8_t *out,
-                 const Geometry &g) {
-    hipLaunchKernelGGL((k_pack<T>), dim3(g.pack_tiles, g.nplanes), dim3(PACK_THREADS), 0, s, planes, k_map,
-                       group_bits, tile_bitoff, tile_bits, image_off, out, g.W, g.H, g.npix, g.pack_tiles,
-                       g.planes_per_image, g.color, g.depth);
+                 const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint64_t *plane_base,
+                 const uint64_t *image_off, uint64_t slot_stride, uint8_t *out, const Geometry &g, uint32_t t0,
+                 uint32_t t1) {
+    if (t1 <= t0) return;
+    Placement pl{image_off, slot_stride};
+    hipLaunchKernelGGL((k_pack<T>), dim3(t1 - t0, g.nplanes), dim3(PACK_THREADS), 0, s, planes, k_map, group_bits,
+                       tile_bitoff, tile_bits, plane_base, pl, out, g.W, g.H, g.npix, g.pack_tiles, g.planes_per_image,
+                       g.color, g.depth, t0);
 }
 template void launch_pack<uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, const uint16_t *, const uint64_t *,
-                                   const uint32_t *, const uint64_t *, uint8_t *, const Geometry &);
+                                   const uint32_t *, const uint64_t *, const uint64_t *, uint64_t, uint8_t *,
+                                   const Geometry &, uint32_t, uint32_t);
 template void launch_pack<int16_t>(hipStream_t, const int16_t *, const uint8_t *, const uint16_t *, const uint64_t *,
-                                   const uint32_t *, const uint64_t *, uint8_t *, const Geometry &);
+                                   const uint32_t *, const uint64_t *, const uint64_t *, uint64_t, uint8_t *,
+                                   const Geometry &, uint32_t, uint32_t);
 
 }  // namespace felics

@@ -21,7 +21,12 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 def enc():
     import felics_amd
 
+    # FELICS_POISON: the library overwrites its whole workspace with garbage before every submission, so a
+    # kernel that consumes a value before the stage that produces it has run cannot pass by finding the
+    # previous submission's (identical) value still in place.
+    os.environ["FELICS_POISON"] = "1"
     e = felics_amd.Encoder(0)  # raises if the HIP device / libfelics.so is missing: no fallback
+    del os.environ["FELICS_POISON"]
     yield e
     e.close()
 
@@ -211,3 +216,20 @@ def test_batch_sizes_and_lanes(enc, oracle):
     want = [oracle.compress(f) for f in frames]
     for n in (1, 7, 8, 16, 25, 37):
         assert enc.compress_batch(frames[:n]) == want[:n], n
+
+
+def test_fresh_context_large_batch(oracle):
+    """A new context (nothing left over from earlier submissions) on inputs big enough for every slice and
+    lane of the pipeline to be in flight at once."""
+    import felics_amd
+    from felics_amd import synth
+
+    frames = [synth.gray8(3840, 2160, f, "S1") for f in range(10)]
+    want = [hashlib.sha256(oracle.compress(f)).hexdigest() for f in frames]
+    for _ in range(2):
+        with felics_amd.Encoder(0) as e:
+            got = e.compress_batch(frames)
+        assert [hashlib.sha256(g).hexdigest() for g in got] == want
+    with felics_amd.Encoder(0) as e:
+        img = synth.rgb8(3840, 2160, 3)
+        assert e.compress(img) == oracle.compress(img)

@@ -22,8 +22,8 @@ namespace {
 enum Stage { ST_PLANES = 0, ST_HIST, ST_OFFSETS, ST_SCATTER, ST_SPINE, ST_ASSIGN, ST_LENGTHS, ST_BITSCAN, ST_ZERO, ST_PACK, ST_COUNT };
 const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "spine", "assign", "lengths", "bitscan", "zero", "pack"};
 
-constexpr int SLICES = 6;               // scatter / spine slices per lane: the spine starts after the first quarter
-constexpr int MAX_LANES = 2;            // sub-batches in flight, three HIP streams each (front, spine, tail)
+constexpr int SLICES = 12;              // scatter / spine slices per lane: the spine starts after the first quarter
+constexpr int MAX_LANES = 2;            // sub-batches in flight, four HIP streams each (front, spine, k, tail)
 constexpr size_t MIN_LANE_IMAGES = 8;   // below this a sub-batch does not fill the GPU
 
 struct DevBuf {
@@ -37,9 +37,11 @@ struct DevBuf {
 struct Lane {
     hipStream_t stream = nullptr;      // spine slices
     hipStream_t front = nullptr;       // planes, hist, offsets, scatter slices
-    hipStream_t tail = nullptr;        // assign slices, lengths, bit scan, pack
+    hipStream_t kstream = nullptr;     // assign slices (k of the events)
+    hipStream_t tail = nullptr;        // lengths, bit scan, pack slices
     hipEvent_t slice_done[SLICES] = {};
     hipEvent_t spine_done[SLICES] = {};
+    hipEvent_t assign_done[SLICES] = {};
     hipEvent_t ev[ST_COUNT][2] = {};
     bool ev_used[ST_COUNT] = {};
     hipEvent_t sized = nullptr;       // stream sizes have landed in h_sizes
@@ -58,7 +60,7 @@ struct Lane {
 
 struct felics_ctx {
     int device = -1;
-    int max_lanes = MAX_LANES;  // FELICS_LANES=1..MAX_LANES overrides (tuning / per-kernel timing)
+    int max_lanes = 1;          // sub-batches in flight; FELICS_LANES=1..MAX_LANES overrides (tuning)
     bool poison = false;        // FELICS_POISON=1: overwrite the workspace before every sub-batch (tests)
     bool trace = false;         // FELICS_TRACE=1: synchronise and report after every stage (debugging)
     int timeout_s = 120;        // FELICS_TIMEOUT_S: give up waiting for a submission after this long
@@ -105,6 +107,7 @@ int sync_all(felics_ctx *ctx) {
     for (Lane &l : ctx->lanes) {
         if (l.front) HIP_TRY(ctx, hipStreamSynchronize(l.front));
         if (l.stream) HIP_TRY(ctx, hipStreamSynchronize(l.stream));
+        if (l.kstream) HIP_TRY(ctx, hipStreamSynchronize(l.kstream));
         if (l.tail) HIP_TRY(ctx, hipStreamSynchronize(l.tail));
     }
     return FELICS_OK;
@@ -218,8 +221,8 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         l.h_sizes_cap = hs;
     }
 
-    hipStream_t s = l.stream, f = l.front, tl = l.tail;
-    if (getenv("FELICS_SERIAL")) f = tl = s;  // debugging aid: one stream, same order of launches
+    hipStream_t s = l.stream, f = l.front, ks = l.kstream, tl = l.tail;
+    if (getenv("FELICS_SERIAL")) f = ks = tl = s;  // debugging aid: one stream, same order of launches
     const T *d_planes = (const T *)l.d_planes;
     auto *counts = (uint32_t *)l.counts.p;
     auto *chain_len = (uint32_t *)l.chain_len.p;
@@ -278,18 +281,23 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
             HIP_TRY(ctx, hipEventRecord(l.spine_done[q], s));
         }
     }
-    // ---- tail stream
-    HIP_TRY(ctx, hipMemsetAsync(plane_carry, 0, (size_t)g.nplanes * 16, tl));
+    // ---- k stream: behind every spine launch, k of the events it published
     for (int q = 0; q < SLICES; q++) {
-        HIP_TRY(ctx, hipStreamWaitEvent(tl, l.spine_done[q], 0));
-        const bool last = q + 1 == SLICES;
-        if (bounds[q + 1] == bounds[q] && !last) continue;
-        {
-            StageTimer t(ctx, l, ST_ASSIGN, tl);
-            launch_assign<ET>(tl, (const ET *)l.sorted_e.p, (const uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
+        HIP_TRY(ctx, hipStreamWaitEvent(ks, l.spine_done[q], 0));
+        if (bounds[q + 1] != bounds[q] || q + 1 == SLICES) {
+            StageTimer t(ctx, l, ST_ASSIGN, ks);
+            launch_assign<ET>(ks, (const ET *)l.sorted_e.p, (const uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
                               (const uint32_t *)l.block_state.p, (const uint32_t *)l.scalars.p,
                               (const uint32_t *)l.block_tag.p, (const uint32_t *)l.partial.p, epoch, (uint32_t)q + 1, g);
         }
+        HIP_TRY(ctx, hipEventRecord(l.assign_done[q], ks));
+    }
+    // ---- tail stream: code lengths, bit offsets and (with fixed slots) the packed bits of each slice's tiles
+    HIP_TRY(ctx, hipMemsetAsync(plane_carry, 0, (size_t)g.nplanes * 16, tl));
+    for (int q = 0; q < SLICES; q++) {
+        HIP_TRY(ctx, hipStreamWaitEvent(tl, l.assign_done[q], 0));
+        const bool last = q + 1 == SLICES;
+        if (bounds[q + 1] == bounds[q] && !last) continue;
         {
             StageTimer t(ctx, l, ST_LENGTHS, tl);
             launch_lengths<T>(tl, d_planes, (const uint8_t *)l.k_map.p, (uint16_t *)l.group_bits.p,
@@ -545,13 +553,19 @@ int felics_ctx_create(int device, felics_ctx **out) {
         if (v >= 1 && v <= MAX_LANES) ctx->max_lanes = v;
     }
     bool ok = hipSetDevice(device) == hipSuccess;
+    // The scatter slices and the spine are the critical path: their streams get the highest priority, so
+    // the kernels that trail behind (k, lengths, pack) do not delay them when the GPU is full.
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);  // numerically: low >= high
     for (Lane &l : ctx->lanes) {
-        ok = ok && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipStreamCreateWithFlags(&l.front, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipStreamCreateWithFlags(&l.tail, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio_high) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&l.front, hipStreamNonBlocking, prio_high) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&l.kstream, hipStreamNonBlocking, prio_low) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&l.tail, hipStreamNonBlocking, prio_low) == hipSuccess;
         for (int q = 0; q < SLICES && ok; q++) {
             ok = hipEventCreateWithFlags(&l.slice_done[q], hipEventDisableTiming) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&l.spine_done[q], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&l.assign_done[q], hipEventDisableTiming) == hipSuccess;
         }
         ok = ok && hipEventCreateWithFlags(&l.sized, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < ST_COUNT && ok; i++)
@@ -571,6 +585,7 @@ void felics_ctx_destroy(felics_ctx *ctx) {
     for (Lane &l : ctx->lanes) {
         if (l.front) (void)hipStreamSynchronize(l.front);
         if (l.stream) (void)hipStreamSynchronize(l.stream);
+        if (l.kstream) (void)hipStreamSynchronize(l.kstream);
         if (l.tail) (void)hipStreamSynchronize(l.tail);
         DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map,
                           &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.plane_sums, &l.image_bytes, &l.image_off,
@@ -584,9 +599,11 @@ void felics_ctx_destroy(felics_ctx *ctx) {
         for (int q = 0; q < SLICES; q++) {
             if (l.slice_done[q]) (void)hipEventDestroy(l.slice_done[q]);
             if (l.spine_done[q]) (void)hipEventDestroy(l.spine_done[q]);
+            if (l.assign_done[q]) (void)hipEventDestroy(l.assign_done[q]);
         }
         if (l.front) (void)hipStreamDestroy(l.front);
         if (l.tail) (void)hipStreamDestroy(l.tail);
+        if (l.kstream) (void)hipStreamDestroy(l.kstream);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     release(ctx->in);

@@ -78,7 +78,8 @@ EXPORTS = [
     "felics_ctx_create", "felics_ctx_destroy", "felics_max_compressed_size", "felics_compress",
     "felics_compress_batch", "felics_compress_batch_device", "felics_read_header", "felics_write_header",
     "felics_decompress", "felics_strerror", "felics_last_error", "felics_set_profiling",
-    "felics_stage_count", "felics_stage_name", "felics_get_stage_ms", "felics_lane_count",
+    "felics_stage_count", "felics_stage_name", "felics_get_stage_ms", "felics_get_stage_launches",
+    "felics_lane_count",
 ]
 
 _lib = None
@@ -135,6 +136,7 @@ def lib():
     L.felics_stage_name.argtypes = [C.c_int]
     L.felics_stage_name.restype = C.c_char_p
     L.felics_get_stage_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
+    L.felics_get_stage_launches.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
     _lib = L
     return L
 
@@ -234,10 +236,17 @@ class Encoder:
         lib().felics_set_profiling(self._h, int(bool(on)))
 
     def stage_ms(self):
+        """Per stage: sum of the durations (ms) of its launches in the last submission."""
         n = lib().felics_stage_count()
         buf = (C.c_float * n)()
         lib().felics_get_stage_ms(self._h, buf, n)
         return {lib().felics_stage_name(i).decode(): float(buf[i]) for i in range(n)}
+
+    def stage_launches(self):
+        n = lib().felics_stage_count()
+        buf = (C.c_int * n)()
+        lib().felics_get_stage_launches(self._h, buf, n)
+        return {lib().felics_stage_name(i).decode(): int(buf[i]) for i in range(n)}
 
 
 _default = {}

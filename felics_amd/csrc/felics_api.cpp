@@ -22,7 +22,8 @@ namespace {
 enum Stage { ST_PLANES = 0, ST_HIST, ST_OFFSETS, ST_SCATTER, ST_SPINE, ST_ASSIGN, ST_LENGTHS, ST_BITSCAN, ST_ZERO, ST_PACK, ST_COUNT };
 const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "spine", "assign", "lengths", "bitscan", "zero", "pack"};
 
-constexpr int SLICES = 12;              // scatter / spine slices per lane: the spine starts after the first quarter
+constexpr int SLICES = 12;
+constexpr int EV_PAIRS = SLICES + 2;     // launches of one stage per sub-batch that can be timed              // scatter / spine slices per lane: the spine starts after the first quarter
 constexpr int MAX_LANES = 2;            // sub-batches in flight, four HIP streams each (front, spine, k, tail)
 constexpr size_t MIN_LANE_IMAGES = 8;   // below this a sub-batch does not fill the GPU
 
@@ -42,8 +43,8 @@ struct Lane {
     hipEvent_t slice_done[SLICES] = {};
     hipEvent_t spine_done[SLICES] = {};
     hipEvent_t assign_done[SLICES] = {};
-    hipEvent_t ev[ST_COUNT][2] = {};
-    bool ev_used[ST_COUNT] = {};
+    hipEvent_t ev[ST_COUNT][EV_PAIRS][2] = {};  // profiling: one start/stop pair per launch of a stage
+    int ev_used[ST_COUNT] = {};                  // pairs used by the current sub-batch
     hipEvent_t sized = nullptr;       // stream sizes have landed in h_sizes
     uint64_t *h_sizes = nullptr;      // pinned: image_bytes[n] followed by image_off[n + 1]
     size_t h_sizes_cap = 0;
@@ -68,6 +69,7 @@ struct felics_ctx {
     std::string err;
     bool profiling = false;
     float stage_ms[ST_COUNT] = {};
+    int stage_launches[ST_COUNT] = {};
     DevBuf in, out;  // staging of the host-pointer entry points
 };
 
@@ -142,19 +144,22 @@ void release(DevBuf &b) {
     b.cap = 0;
 }
 
+// Brackets one launch (or a few back-to-back launches) of a stage with HIP events on the stream it runs
+// on; a stage's time is the sum over its launches of a sub-batch.
 struct StageTimer {
     felics_ctx *ctx;
     Lane &lane;
     int st;
     hipStream_t stream;
+    int slot = -1;
     StageTimer(felics_ctx *c, Lane &l, int s, hipStream_t on) : ctx(c), lane(l), st(s), stream(on) {
-        if (ctx->profiling && !lane.ev_used[st]) {  // a stage launched slice by slice is timed first start to last stop
-            (void)hipEventRecord(lane.ev[st][0], stream);
-            lane.ev_used[st] = true;
+        if (ctx->profiling && lane.ev_used[st] < EV_PAIRS) {
+            slot = lane.ev_used[st]++;
+            (void)hipEventRecord(lane.ev[st][slot][0], stream);
         }
     }
     ~StageTimer() {
-        if (ctx->profiling) (void)hipEventRecord(lane.ev[st][1], stream);
+        if (slot >= 0) (void)hipEventRecord(lane.ev[st][slot][1], stream);
         if (ctx->trace) {  // FELICS_TRACE: wait for the stage and say so (locating a kernel that does not return)
             hipError_t e = hipStreamSynchronize(stream);
             fprintf(stderr, "[felics] %s done (%s)\n", kStageNames[st], hipGetErrorString(e));
@@ -260,26 +265,24 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         bounds[q] = (uint32_t)((uint64_t)g.sort_tiles * q / SLICES);
         pbounds[q] = q == SLICES ? g.pack_tiles : std::min<uint32_t>(g.pack_tiles, bounds[q] * (SORT_TILE / PACK_TILE));
     }
-    {
-        StageTimer t(ctx, l, ST_SCATTER, f);
-        for (int q = 0; q < SLICES; q++) {
+    for (int q = 0; q < SLICES; q++) {
+        if (bounds[q + 1] != bounds[q]) {
+            StageTimer t(ctx, l, ST_SCATTER, f);
             launch_scatter<T, ET>(f, d_planes, counts, chain_base, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, g,
                                   bounds[q], bounds[q + 1]);
-            HIP_TRY(ctx, hipEventRecord(l.slice_done[q], f));
         }
+        HIP_TRY(ctx, hipEventRecord(l.slice_done[q], f));
     }
     // ---- spine stream
-    HIP_TRY(ctx, hipStreamWaitEvent(s, l.slice_done[0], 0));
-    {
-        StageTimer t(ctx, l, ST_SPINE, s);
-        for (int q = 0; q < SLICES; q++) {
-            if (q) HIP_TRY(ctx, hipStreamWaitEvent(s, l.slice_done[q], 0));
-            if (bounds[q + 1] != bounds[q] || q + 1 == SLICES)
-                launch_spine<ET>(s, (const ET *)l.sorted_e.p, (uint32_t *)l.block_state.p, chain_base, chain_len, counts,
-                                 bounds[q + 1], chain_prog, (uint32_t *)l.block_tag.p, (uint32_t *)l.partial.p, epoch,
-                                 (uint32_t)q + 1, g);
-            HIP_TRY(ctx, hipEventRecord(l.spine_done[q], s));
+    for (int q = 0; q < SLICES; q++) {
+        HIP_TRY(ctx, hipStreamWaitEvent(s, l.slice_done[q], 0));
+        if (bounds[q + 1] != bounds[q] || q + 1 == SLICES) {
+            StageTimer t(ctx, l, ST_SPINE, s);
+            launch_spine<ET>(s, (const ET *)l.sorted_e.p, (uint32_t *)l.block_state.p, chain_base, chain_len, counts,
+                             bounds[q + 1], chain_prog, (uint32_t *)l.block_tag.p, (uint32_t *)l.partial.p, epoch,
+                             (uint32_t)q + 1, g);
         }
+        HIP_TRY(ctx, hipEventRecord(l.spine_done[q], s));
     }
     // ---- k stream: behind every spine launch, k of the events it published
     for (int q = 0; q < SLICES; q++) {
@@ -355,11 +358,16 @@ int pack_exact(felics_ctx *ctx, Lane &l, uint8_t *d_out) {
 void collect_timing(felics_ctx *ctx) {
     if (!ctx->profiling) return;
     for (int i = 0; i < ST_COUNT; i++) {
-        ctx->stage_ms[i] = 0.f;  // sum over the lanes (lanes overlap: the sum can exceed wall time)
-        for (Lane &l : ctx->lanes) {
-            float ms = 0.f;
-            if (l.ev_used[i] && hipEventElapsedTime(&ms, l.ev[i][0], l.ev[i][1]) == hipSuccess) ctx->stage_ms[i] += ms;
-        }
+        ctx->stage_ms[i] = 0.f;  // sum of the launches' durations (launches overlap: the sum can exceed wall time)
+        ctx->stage_launches[i] = 0;
+        for (Lane &l : ctx->lanes)
+            for (int k = 0; k < l.ev_used[i]; k++) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, l.ev[i][k][0], l.ev[i][k][1]) == hipSuccess) {
+                    ctx->stage_ms[i] += ms;
+                    ctx->stage_launches[i]++;
+                }
+            }
     }
 }
 
@@ -380,7 +388,7 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
     if (npix * planes >= 0xE0000000ull) return FELICS_E_UNSUPPORTED;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (Lane &l : ctx->lanes)
-        for (int i = 0; i < ST_COUNT; i++) l.ev_used[i] = false;
+        for (int i = 0; i < ST_COUNT; i++) l.ev_used[i] = 0;
     const bool own_out = d_out == nullptr;
 
     if (npix == 0) {
@@ -569,7 +577,8 @@ int felics_ctx_create(int device, felics_ctx **out) {
         }
         ok = ok && hipEventCreateWithFlags(&l.sized, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < ST_COUNT && ok; i++)
-            for (int j = 0; j < 2 && ok; j++) ok = hipEventCreate(&l.ev[i][j]) == hipSuccess;
+            for (int k = 0; k < EV_PAIRS && ok; k++)
+                for (int j = 0; j < 2 && ok; j++) ok = hipEventCreate(&l.ev[i][k][j]) == hipSuccess;
     }
     if (!ok) {
         felics_ctx_destroy(ctx);
@@ -593,8 +602,9 @@ void felics_ctx_destroy(felics_ctx *ctx) {
         for (DevBuf *b : bufs) release(*b);
         if (l.h_sizes) (void)hipHostFree(l.h_sizes);
         for (int i = 0; i < ST_COUNT; i++)
-            for (int j = 0; j < 2; j++)
-                if (l.ev[i][j]) (void)hipEventDestroy(l.ev[i][j]);
+            for (int k = 0; k < EV_PAIRS; k++)
+                for (int j = 0; j < 2; j++)
+                    if (l.ev[i][k][j]) (void)hipEventDestroy(l.ev[i][k][j]);
         if (l.sized) (void)hipEventDestroy(l.sized);
         for (int q = 0; q < SLICES; q++) {
             if (l.slice_done[q]) (void)hipEventDestroy(l.slice_done[q]);
@@ -722,6 +732,13 @@ int felics_set_profiling(felics_ctx *ctx, int enabled) {
 int felics_stage_count(void) { return ST_COUNT; }
 
 int felics_lane_count(void) { return MAX_LANES; }
+
+int felics_get_stage_launches(const felics_ctx *ctx, int *launches, int cap) {
+    if (!ctx || !launches) return FELICS_E_INVALID_ARGUMENT;
+    int n = cap < ST_COUNT ? cap : (int)ST_COUNT;
+    for (int i = 0; i < n; i++) launches[i] = ctx->stage_launches[i];
+    return n;
+}
 
 const char *felics_stage_name(int stage) { return stage >= 0 && stage < ST_COUNT ? kStageNames[stage] : ""; }
 

@@ -117,16 +117,18 @@ const char *felics_strerror(int code);
 const char *felics_last_error(const felics_ctx *ctx);
 
 /* ---- measurement hooks (bench.py) ----
- * With profiling on, every kernel of the next submission is bracketed by HIP
- * events on the context's stream; felics_get_stage_ms copies the last
- * submission's per-stage milliseconds (names via felics_stage_name). */
+ * With profiling on, every kernel launch of the next submission is bracketed by HIP events on the
+ * stream it runs on.  A submission launches most kernels once per slice of the image (the stages
+ * follow each other slice by slice on several streams); felics_get_stage_ms gives, per stage, the SUM
+ * of its launches' durations in milliseconds (launches of different stages overlap, so the stages add
+ * up to more than the wall time), felics_get_stage_launches how many launches that was. */
 #define FELICS_MAX_STAGES 16
 int felics_set_profiling(felics_ctx *ctx, int enabled);
 int felics_stage_count(void);
 const char *felics_stage_name(int stage);
 int felics_get_stage_ms(const felics_ctx *ctx, float *ms, int cap);
-/* A submission is split into up to this many sub-batches, each on its own HIP stream; a stage's
- * milliseconds are summed over them (they overlap, so the sum can exceed wall time). */
+int felics_get_stage_launches(const felics_ctx *ctx, int *launches, int cap);
+/* Upper bound of the sub-batches one submission is split into (each with its own streams). */
 int felics_lane_count(void);
 
 #ifdef __cplusplus

@@ -12,7 +12,7 @@ namespace felics {
 // u8 samples (and Y/Co/Cg of RGB8): contexts 0..510 (traits.rs:28), table padded to 512.
 constexpr uint32_t NCTX = 512;
 // pixels one wave partitions by context in the hist / scatter stages
-constexpr uint32_t SORT_TILE = 16384;
+constexpr uint32_t SORT_TILE = 8192;
 // pack stage: 256 threads x 16 consecutive pixels
 constexpr uint32_t PACK_THREADS = 256;
 constexpr uint32_t PACK_PER_THREAD = 16;

@@ -160,14 +160,26 @@ __global__ __launch_bounds__(256) void k_hist(const T *__restrict__ planes, uint
         const T *pl = planes + (uint64_t)plane * npix;
         const uint32_t begin = tile * SORT_TILE;
         const uint32_t end = min(begin + SORT_TILE, npix);
+        // Four rows per trip: the twelve loads of a trip are in flight together (the kernel is bound by
+        // their latency, not by the atomics).
         Coord xy;
         xy.set(begin + lane, W);
-        for (uint32_t i = begin + lane; i < end; i += 64) {
-            if (i >= 2) {
-                PixelClass pc = classify(pl, i, xy.x, xy.y, W);
-                if (pc.cls != CLS_IN) atomicAdd(&hist[wave][pc.ctx], 1u);
+        for (uint32_t i0 = begin + lane; i0 < end; i0 += 256) {
+            PixelClass pc[4];
+            bool ev[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t i = i0 + u * 64;
+                ev[u] = false;
+                if (i < end && i >= 2) {
+                    pc[u] = classify(pl, i, xy.x, xy.y, W);
+                    ev[u] = pc[u].cls != CLS_IN;
+                }
+                xy.advance(64, W);
             }
-            xy.advance(64, W);
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++)
+                if (ev[u]) atomicAdd(&hist[wave][pc[u].ctx], 1u);
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t *dst = counts + ((uint64_t)plane * ntiles + tile) * NCTX;
@@ -297,13 +309,20 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
         // by HOT independent ballots; whatever is left goes through the one-context-per-trip loop.
         uint32_t rank = 0, group = 0;
         constexpr uint32_t HOT = 8;
+        {
+            // every lane picks the ballot of its own context out of the HOT ballots (two selects per
+            // context), then ranks itself against that mask once
+            uint32_t sel_lo = 0, sel_hi = 0;
 #pragma unroll
-        for (uint32_t t = 0; t < HOT; t++) {
-            const bool mine = ev && c == t;
-            const uint64_t m = __ballot(mine);
-            if (mine) {
-                rank = mbcnt(m);
-                group = (uint32_t)__popcll(m);
+            for (uint32_t t = 0; t < HOT; t++) {
+                const bool is_t = c == t;
+                const uint64_t m = __ballot(ev && is_t);
+                sel_lo = is_t ? (uint32_t)m : sel_lo;
+                sel_hi = is_t ? (uint32_t)(m >> 32) : sel_hi;
+            }
+            if (ev && c < HOT) {
+                rank = __builtin_amdgcn_mbcnt_hi(sel_hi, __builtin_amdgcn_mbcnt_lo(sel_lo, 0u));
+                group = (uint32_t)__popc(sel_lo) + (uint32_t)__popc(sel_hi);
             }
         }
         uint64_t pending = __ballot(ev && c >= HOT);

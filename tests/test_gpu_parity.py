@@ -233,3 +233,46 @@ def test_fresh_context_large_batch(oracle):
     with felics_amd.Encoder(0) as e:
         img = synth.rgb8(3840, 2160, 3)
         assert e.compress(img) == oracle.compress(img)
+
+
+def test_slot_overflow_falls_back_to_exact_placement(enc, oracle):
+    """felics_compress_batch_device gives every stream a fixed slot of capacity / n bytes.  A stream that
+    does not fit its slot makes the library lay the streams out back to back instead; if even that does
+    not fit, FELICS_E_BUFFER_TOO_SMALL reports the capacity needed."""
+    import torch
+
+    import felics_amd
+    from felics_amd import synth
+
+    w, h = 512, 384
+    frames = [synth.gray8(w, h, 0, "S3"), synth.gray8(w, h, 1, "S2"), synth.gray8(w, h, 2, "S3"), synth.gray8(w, h, 3, "S1")]
+    want = [oracle.compress(f) for f in frames]
+    assert len(want[1]) > w * h  # the noise frame expands
+    d_in = torch.from_numpy(np.stack(frames)).cuda()
+    cap = 4 * ((len(want[1]) - 4096) // 16 * 16)  # slot a little smaller than the noise stream
+    assert sum((len(x) + 15) // 16 * 16 for x in want) <= cap
+    d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    offs, lens = enc.compress_batch_device(d_in.data_ptr(), 4, w, h, 0, 0, d_out.data_ptr(), cap)
+    host = d_out.cpu().numpy()
+    assert all(int(o) % 16 == 0 for o in offs) and list(offs) == sorted(offs)
+    assert offs[1] != cap // 4 // 16 * 16  # not the slot layout any more
+    for i in range(4):
+        assert host[int(offs[i]): int(offs[i] + lens[i])].tobytes() == want[i], i
+    # capacity below the exact need: an error that says how much is needed
+    small = sum((len(x) + 15) // 16 * 16 for x in want) - 1024
+    with pytest.raises(felics_amd.FelicsError) as ei:
+        enc.compress_batch_device(d_in.data_ptr(), 4, w, h, 0, 0, d_out.data_ptr(), small)
+    assert ei.value.code == -8 and "need" in str(ei.value)
+    # rgb through the same fallback
+    rgb = [synth.rgb8(256, 200, f) for f in range(3)]
+    rgb[1] = np.random.default_rng(5).integers(0, 256, size=(200, 256, 3), dtype=np.uint8)
+    want = [oracle.compress(f) for f in rgb]
+    d_in = torch.from_numpy(np.stack(rgb)).cuda()
+    cap = 3 * ((len(want[1]) - 2048) // 16 * 16)
+    d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    offs, lens = enc.compress_batch_device(d_in.data_ptr(), 3, 256, 200, 1, 0, d_out.data_ptr(), cap)
+    host = d_out.cpu().numpy()
+    for i in range(3):
+        assert host[int(offs[i]): int(offs[i] + lens[i])].tobytes() == want[i], i

@@ -325,17 +325,24 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
                 group = (uint32_t)__popc(sel_lo) + (uint32_t)__popc(sel_hi);
             }
         }
-        uint64_t pending = __ballot(ev && c >= HOT);
-        while (pending) {
-            const uint32_t src = (uint32_t)__ffsll((long long)pending) - 1u;
-            const uint32_t cc = readlane(c, src);
-            const bool mine = ev && c == cc;
-            const uint64_t m = __ballot(mine);
-            if (mine) {
-                rank = mbcnt(m);
-                group = (uint32_t)__popcll(m);
+        // Whatever is left (contexts >= HOT) is matched bit by bit: after the nine ballots below every
+        // lane holds the mask of the lanes whose context equals its own -- a fixed cost, however many
+        // different contexts the row holds (busy images have 10-40 per row).
+        const bool rest = ev && c >= HOT;
+        const uint64_t rest_mask = __ballot(rest);
+        if (rest_mask != 0) {
+            uint32_t m_lo = (uint32_t)rest_mask, m_hi = (uint32_t)(rest_mask >> 32);
+#pragma unroll
+            for (uint32_t b = 0; b < 9; b++) {  // contexts are < 512
+                const uint32_t t = (uint32_t)((int32_t)(c << (31 - b)) >> 31);  // all ones if bit b of c is set
+                const uint64_t bb = __ballot(rest && t != 0);
+                m_lo &= ~((uint32_t)bb ^ t);
+                m_hi &= ~((uint32_t)(bb >> 32) ^ t);
             }
-            pending &= ~m;
+            if (rest) {
+                rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+                group = (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);
+            }
         }
         const bool leader = ev && rank == 0;  // first lane of its context in this row
         // one LDS read per lane (same context -> same address -> broadcast), one write per leader

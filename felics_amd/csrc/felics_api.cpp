@@ -236,7 +236,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     auto *plane_carry = (uint64_t *)l.plane_sums.p;
     auto *plane_base = plane_carry + g.nplanes;
     // tags of other sub-batches never match this epoch (the lane's tags are cleared when the counter wraps)
-    if (++l.epoch >= 0x0FFFFFFFu) {
+    if (++l.epoch >= 0x03FFFFFFu) {
         HIP_TRY(ctx, hipMemset(l.block_tag.p, 0, l.block_tag.cap));
         l.epoch = 1;
     }

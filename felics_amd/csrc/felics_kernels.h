@@ -63,8 +63,8 @@ template <typename ET>
 void launch_zero_padding(hipStream_t s, ET *sorted_e, uint32_t *pix_of, const uint32_t *chain_base,
                          const uint32_t *chain_len, const Geometry &g);
 
-// block_tag[b] = epoch << 4 | slice of the spine launch that resolved block b (4 bytes per 64-event block,
-// zero-initialised once; epoch in 1 .. 2^28 - 1, slice in 1..15).  partial = uint2[slices][chains]:
+// block_tag[b] = epoch << 5 | slice of the spine launch that resolved block b (4 bytes per 64-event block,
+// zero-initialised once; epoch in 1 .. 2^26 - 1, slice in 1..31).  partial = uint2[slices][chains]:
 // {block, events in place} of the chain's not-yet-full block after that slice (zeroed per sub-batch).
 template <typename ET>
 void launch_spine(hipStream_t s, const ET *sorted_e, uint32_t *block_state, const uint32_t *chain_base,

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
 // one block that has events in place but is not full yet (partial[chain] = {block, events}).  Later spine
 // launches may already be running: they tag other blocks and rewrite a partial block's record with the
 // same values, so nothing read here is in flux.  Waves scan 64 tags / 64 list entries at a time.
-constexpr uint32_t TAG_SLICE_BITS = 4;  // tag = epoch << 4 | slice
+constexpr uint32_t TAG_SLICE_BITS = 5;  // tag = epoch << 4 | slice
 
 __device__ __forceinline__ void assign_block(const uint4 *__restrict__ st, const uint32_t gb, const uint32_t valid,
                                              const uint32_t e, const uint32_t pix, uint8_t *__restrict__ k_map) {

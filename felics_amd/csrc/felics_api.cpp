@@ -19,8 +19,11 @@ using namespace felics;
 
 namespace {
 
-enum Stage { ST_PLANES = 0, ST_HIST, ST_OFFSETS, ST_SCATTER, ST_SPINE, ST_ASSIGN, ST_LENGTHS, ST_BITSCAN, ST_ZERO, ST_PACK, ST_COUNT };
-const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "spine", "assign", "lengths", "bitscan", "zero", "pack"};
+enum Stage { ST_PLANES = 0, ST_HIST, ST_OFFSETS, ST_SCATTER, ST_SPINE, ST_ASSIGN, ST_LENGTHS, ST_BITSCAN, ST_ZERO, ST_PACK,
+             ST_WIDE_KEYS, ST_WIDE_SORT, ST_WIDE_CHAINS, ST_COUNT };
+const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "spine", "assign", "lengths", "bitscan", "zero", "pack",
+                                     "wide_keys", "wide_sort", "wide_chains"};
+static_assert(ST_COUNT <= FELICS_MAX_STAGES, "felics.h promises at most FELICS_MAX_STAGES stages");
 
 constexpr int SLICES = 12;
 constexpr int EV_PAIRS = SLICES + 2;     // launches of one stage per sub-batch that can be timed              // scatter / spine slices per lane: the spine starts after the first quarter
@@ -50,6 +53,7 @@ struct Lane {
     size_t h_sizes_cap = 0;
     DevBuf planes, counts, chain_len, chain_base, chain_prog, scalars, sorted_e, pix_of, k_map, block_state, group_bits,
         tile_bits, tile_bitoff, plane_sums, image_bytes, image_off, partial, block_tag;
+    DevBuf wkeys[2], wvals[2], e_of, heads, sort_temp;  // 16-bit samples: sort records, Rice operands, chain heads
     uint32_t epoch = 0;               // sub-batches this lane has run: block tags are (epoch, slice)
     // the sub-batch in flight
     Geometry g;
@@ -333,6 +337,98 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     return FELICS_OK;
 }
 
+// 16-bit samples (T = u16 gray planes, i32 Y/Co/Cg planes): everything on the lane's main stream.
+//   keys -> stable sort by (plane, context) -> chain heads -> estimator replay per chain (k_map)
+//   -> lengths, bit scan, sizes -> pack (fixed slots) ; same contract as run_lane towards the caller.
+template <typename T>
+int run_wide(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
+    const Geometry &g = l.g;
+    const size_t nsamples = (size_t)g.nplanes * g.npix;
+    uint32_t plane_bits = 0;
+    while ((1u << plane_bits) < g.nplanes) plane_bits++;
+    const uint32_t key_bits = WIDE_CTX_BITS + plane_bits;
+    const size_t temp_bytes = wide_sort_temp_bytes(nsamples, key_bits);
+    int rc;
+    for (int i = 0; i < 2; i++) {
+        if ((rc = reserve(ctx, l.wkeys[i], nsamples * 4)) != 0) return rc;
+        if ((rc = reserve(ctx, l.wvals[i], nsamples * 4)) != 0) return rc;
+    }
+    if ((rc = reserve(ctx, l.e_of, nsamples * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.heads, nsamples * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.sort_temp, temp_bytes + 256)) != 0) return rc;
+    if ((rc = reserve(ctx, l.scalars, 64)) != 0) return rc;
+    if ((rc = reserve(ctx, l.k_map, nsamples + STAGE_PAD)) != 0) return rc;
+    if ((rc = reserve(ctx, l.group_bits, (size_t)g.nplanes * g.pack_tiles * PACK_THREADS * sizeof(group_bits_t<T>))) != 0) return rc;
+    if ((rc = reserve(ctx, l.tile_bits, (size_t)g.nplanes * g.pack_tiles * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.tile_bitoff, (size_t)g.nplanes * g.pack_tiles * 8)) != 0) return rc;
+    if ((rc = reserve(ctx, l.plane_sums, (size_t)g.nplanes * 16)) != 0) return rc;
+    if ((rc = reserve(ctx, l.image_bytes, (size_t)g.nimages * 8)) != 0) return rc;
+    if ((rc = reserve(ctx, l.image_off, (size_t)(g.nimages + 1) * 8)) != 0) return rc;
+    const size_t hs = (size_t)g.nimages * 2 + 1;
+    if (hs > l.h_sizes_cap) {
+        if (l.h_sizes) HIP_TRY(ctx, hipHostFree(l.h_sizes));
+        l.h_sizes = nullptr;
+        HIP_TRY(ctx, hipHostMalloc((void **)&l.h_sizes, hs * 8 + 64, hipHostMallocDefault));
+        l.h_sizes_cap = hs;
+    }
+    hipStream_t s = l.stream;
+    const T *d_planes = (const T *)l.d_planes;
+    auto *plane_carry = (uint64_t *)l.plane_sums.p;
+    auto *plane_base = plane_carry + g.nplanes;
+    auto *nheads = (uint32_t *)l.scalars.p;
+    if (ctx->poison) {
+        DevBuf *bufs[] = {&l.wkeys[0], &l.wkeys[1], &l.wvals[0], &l.wvals[1], &l.e_of, &l.heads, &l.k_map,
+                          &l.group_bits, &l.tile_bits, &l.tile_bitoff};
+        for (DevBuf *b : bufs) HIP_TRY(ctx, hipMemsetAsync(b->p, 0xA5, b->cap, s));
+    }
+    uint32_t *skeys = nullptr, *svals = nullptr;
+    {
+        StageTimer t(ctx, l, ST_WIDE_KEYS, s);
+        launch_wide_keys<T>(s, d_planes, (uint32_t *)l.wkeys[0].p, (uint32_t *)l.wvals[0].p, (uint32_t *)l.e_of.p, g);
+    }
+    {
+        StageTimer t(ctx, l, ST_WIDE_SORT, s);
+        HIP_TRY(ctx, wide_sort(s, l.sort_temp.p, temp_bytes, (uint32_t *)l.wkeys[0].p, (uint32_t *)l.wkeys[1].p,
+                               (uint32_t *)l.wvals[0].p, (uint32_t *)l.wvals[1].p, nsamples, key_bits, &skeys, &svals));
+    }
+    {
+        StageTimer t(ctx, l, ST_WIDE_CHAINS, s);
+        HIP_TRY(ctx, hipMemsetAsync(nheads, 0, 4, s));
+        launch_wide_heads(s, skeys, (uint32_t)nsamples, (uint32_t *)l.heads.p, nheads);
+        launch_wide_chains(s, skeys, svals, (const uint32_t *)l.e_of.p, (uint32_t)nsamples, (const uint32_t *)l.heads.p,
+                           nheads, (uint8_t *)l.k_map.p);
+    }
+    HIP_TRY(ctx, hipMemsetAsync(plane_carry, 0, (size_t)g.nplanes * 16, s));
+    {
+        StageTimer t(ctx, l, ST_LENGTHS, s);
+        launch_lengths<T>(s, d_planes, (const uint8_t *)l.k_map.p, (group_bits_t<T> *)l.group_bits.p,
+                          (uint32_t *)l.tile_bits.p, g, 0, g.pack_tiles);
+    }
+    {
+        StageTimer t(ctx, l, ST_BITSCAN, s);
+        launch_bitscan_slice(s, (const uint32_t *)l.tile_bits.p, (uint64_t *)l.tile_bitoff.p, plane_carry, g, 0,
+                             g.pack_tiles);
+        launch_finish_sizes(s, plane_carry, plane_base, (uint64_t *)l.image_bytes.p, g);
+    }
+    if (slot_stride != 0) {
+        {
+            StageTimer t(ctx, l, ST_ZERO, s);
+            launch_zero_edges(s, d_out, nullptr, slot_stride, (const uint64_t *)l.tile_bitoff.p,
+                              (const uint32_t *)l.tile_bits.p, plane_base, g, 0, g.pack_tiles);
+        }
+        {
+            StageTimer t(ctx, l, ST_PACK, s);
+            launch_pack<T>(s, d_planes, (const uint8_t *)l.k_map.p, (const group_bits_t<T> *)l.group_bits.p,
+                           (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p, plane_base, nullptr,
+                           slot_stride, d_out, g, 0, g.pack_tiles);
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(l.h_sizes, l.image_bytes.p, (size_t)g.nimages * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipEventRecord(l.sized, s));
+    return FELICS_OK;
+}
+
 // Exact placement: streams back to back at image_off (computed on the device from the sizes), every
 // byte of them zeroed, all tiles packed.  Used when the streams do not get fixed slots, and to redo a
 // sub-batch in which a stream outgrew its slot.
@@ -347,7 +443,7 @@ int pack_exact(felics_ctx *ctx, Lane &l, uint8_t *d_out) {
     }
     {
         StageTimer t(ctx, l, ST_PACK, s);
-        launch_pack<T>(s, (const T *)l.d_planes, (const uint8_t *)l.k_map.p, (const uint16_t *)l.group_bits.p,
+        launch_pack<T>(s, (const T *)l.d_planes, (const uint8_t *)l.k_map.p, (const group_bits_t<T> *)l.group_bits.p,
                        (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p, plane_base,
                        (const uint64_t *)l.image_off.p, 0, d_out, g, 0, g.pack_tiles);
     }
@@ -371,10 +467,12 @@ void collect_timing(felics_ctx *ctx) {
     }
 }
 
-// images per pass so that slots / chain bases stay below 2^32
-size_t max_images_per_pass(uint64_t npix, uint32_t planes) {
+// images per pass so that slots / chain bases (8-bit) or sample indices and sort keys (16-bit) stay below 2^32
+size_t max_images_per_pass(uint64_t npix, uint32_t planes, int depth) {
     const uint64_t per_image = npix * planes;
     if (per_image == 0) return SIZE_MAX;
+    if (depth == FELICS_DEPTH_16)  // ~29 bytes of workspace per sample: keep a pass near 2^30 samples
+        return (size_t)std::max<uint64_t>(1, std::min<uint64_t>(0x40000000ull / per_image, WIDE_MAX_PLANES / planes));
     return (size_t)std::max<uint64_t>(1, 0xE0000000ull / (per_image + 64ull * planes * NCTX));
 }
 
@@ -384,7 +482,7 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
                   uint8_t *d_out, size_t d_out_cap, uint64_t *offsets, uint64_t *lens, uint8_t **used_out) {
     const uint32_t planes = color == FELICS_COLOR_RGB ? 3 : 1;
     const uint64_t npix = (uint64_t)w * h;
-    if (depth == FELICS_DEPTH_16) return FELICS_E_UNSUPPORTED;  // GPU path: 8-bit samples
+    const bool wide = depth == FELICS_DEPTH_16;
     if (npix * planes >= 0xE0000000ull) return FELICS_E_UNSUPPORTED;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (Lane &l : ctx->lanes)
@@ -417,8 +515,8 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
         return FELICS_OK;
     }
 
-    const size_t frame_bytes = (size_t)npix * planes;  // u8 samples
-    const size_t per_pass = max_images_per_pass(npix, planes);
+    const size_t frame_bytes = (size_t)npix * planes * (wide ? 2 : 1);
+    const size_t per_pass = max_images_per_pass(npix, planes, depth);
     int rc;
     // Placement.  Preferred: every stream gets a fixed slot (stream i at i * slot), so packing needs no
     // size from the host and follows the spine slice by slice.  If a stream outgrows its slot, or the
@@ -442,7 +540,7 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
         // Rounds of up to max_lanes sub-batches (one round unless the batch is huge).
         while (done < n && !overflow) {
             const size_t left = n - done;
-            const size_t nl = std::min<size_t>((size_t)ctx->max_lanes, std::max<size_t>(1, left / MIN_LANE_IMAGES));
+            const size_t nl = wide ? 1 : std::min<size_t>((size_t)ctx->max_lanes, std::max<size_t>(1, left / MIN_LANE_IMAGES));
             // Later lanes get fewer images (weights nl, nl-1, .., 1): every lane pays the same spine
             // latency, so the lane that starts last should have the least work left after its spine.
             const size_t wsum = nl * (nl + 1) / 2;
@@ -467,15 +565,21 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
                 const uint8_t *src = (const uint8_t *)d_pixels + first * frame_bytes;
                 l.d_planes = src;
                 if (planes == 3) {
-                    if ((rc = reserve(ctx, l.planes, (size_t)g.nplanes * npix * 2 + STAGE_PAD)) != 0) return rc;
-                    hipStream_t fs = getenv("FELICS_SERIAL") ? l.stream : l.front;
+                    if ((rc = reserve(ctx, l.planes, (size_t)g.nplanes * npix * (wide ? 4 : 2) + STAGE_PAD)) != 0) return rc;
+                    hipStream_t fs = wide || getenv("FELICS_SERIAL") ? l.stream : l.front;
                     StageTimer t(ctx, l, ST_PLANES, fs);
-                    launch_rgb8_to_planes(fs, src, (int16_t *)l.planes.p, g.npix, g.nimages);
+                    if (wide)
+                        launch_rgb16_to_planes(fs, (const uint16_t *)src, (int32_t *)l.planes.p, g.npix, g.nimages);
+                    else
+                        launch_rgb8_to_planes(fs, src, (int16_t *)l.planes.p, g.npix, g.nimages);
                     l.d_planes = l.planes.p;
                 }
                 uint8_t *lane_out = d_out + first * slot;
-                rc = planes == 3 ? run_lane<int16_t, uint16_t>(ctx, l, lane_out, slot)
-                                 : run_lane<uint8_t, uint8_t>(ctx, l, lane_out, slot);
+                if (wide)
+                    rc = planes == 3 ? run_wide<int32_t>(ctx, l, lane_out, slot) : run_wide<uint16_t>(ctx, l, lane_out, slot);
+                else
+                    rc = planes == 3 ? run_lane<int16_t, uint16_t>(ctx, l, lane_out, slot)
+                                     : run_lane<uint8_t, uint8_t>(ctx, l, lane_out, slot);
                 if (rc) {
                     (void)sync_all(ctx);
                     return rc;
@@ -514,7 +618,10 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
                     Lane &l = ctx->lanes[li];
                     launch_place_streams(l.tail, (const uint64_t *)l.image_bytes.p, (uint64_t *)l.image_off.p, l.g);
                     uint8_t *lane_out = d_out + offsets[l.first_image];
-                    rc = planes == 3 ? pack_exact<int16_t>(ctx, l, lane_out) : pack_exact<uint8_t>(ctx, l, lane_out);
+                    if (wide)
+                        rc = planes == 3 ? pack_exact<int32_t>(ctx, l, lane_out) : pack_exact<uint16_t>(ctx, l, lane_out);
+                    else
+                        rc = planes == 3 ? pack_exact<int16_t>(ctx, l, lane_out) : pack_exact<uint8_t>(ctx, l, lane_out);
                     if (rc) {
                         (void)sync_all(ctx);
                         return rc;
@@ -598,7 +705,8 @@ void felics_ctx_destroy(felics_ctx *ctx) {
         if (l.tail) (void)hipStreamSynchronize(l.tail);
         DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map,
                           &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.plane_sums, &l.image_bytes, &l.image_off,
-                          &l.partial, &l.block_tag};
+                          &l.partial, &l.block_tag, &l.wkeys[0], &l.wkeys[1], &l.wvals[0], &l.wvals[1], &l.e_of, &l.heads,
+                          &l.sort_temp};
         for (DevBuf *b : bufs) release(*b);
         if (l.h_sizes) (void)hipHostFree(l.h_sizes);
         for (int i = 0; i < ST_COUNT; i++)
@@ -644,11 +752,10 @@ int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, 
     int rc = check_args(w, h, color, depth);
     if (rc) return rc;
     if (n == 0) return FELICS_OK;
-    if (depth == FELICS_DEPTH_16) return FELICS_E_UNSUPPORTED;
     const uint32_t planes = color == FELICS_COLOR_RGB ? 3 : 1;
-    const size_t frame_bytes = (size_t)w * h * planes;
+    const size_t frame_bytes = (size_t)w * h * planes * (depth == FELICS_DEPTH_16 ? 2 : 1);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t per_pass = max_images_per_pass((uint64_t)w * h, planes);
+    const size_t per_pass = max_images_per_pass((uint64_t)w * h, planes, depth);
     std::vector<uint64_t> offs, sizes;
     int result = FELICS_OK;
     for (size_t first = 0; first < n; first += per_pass) {

@@ -1,0 +1,104 @@
+// felics_device.h -- device-side helpers shared by the kernel translation units
+// (felics_kernels.hip: 8-bit pipeline and the code builder; felics_wide.hip: 16-bit front end).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace felics {
+
+// ------------------------------------------------------------------------------------------
+// wave helpers
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    return (1ull << lane_id()) - 1ull;
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave, DPP only (no LDS):
+// 4 row_shr steps inside each row of 16, then row_bcast:15 / row_bcast:31 across rows.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+__device__ __forceinline__ uint32_t readlane(uint32_t v, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+
+// number of set bits of m below this lane
+__device__ __forceinline__ uint32_t mbcnt(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// ------------------------------------------------------------------------------------------
+// per-pixel classification shared by hist / scatter / lengths / pack
+// ------------------------------------------------------------------------------------------
+
+enum : uint32_t { CLS_IN = 0, CLS_BELOW = 1, CLS_ABOVE = 2 };
+
+struct PixelClass {
+    uint32_t cls;  // CLS_*
+    uint32_t ctx;  // H - L
+    uint32_t val;  // p-L (in range), L-p-1 (below), p-H-1 (above)
+};
+
+// The two already-coded neighbours of pixel i = y*W + x, i >= 2 (misc.rs:6-24).
+template <typename T>
+__device__ __forceinline__ PixelClass classify(const T *__restrict__ pl, uint32_t i, uint32_t x,
+                                               uint32_t y, uint32_t W) {
+    uint32_t a, b;
+    if (x > 0 && y > 0) {
+        a = i - 1;
+        b = i - W;
+    } else if (y == 0) {  // first row, x >= 2 because i >= 2
+        a = i - 1;
+        b = i - 2;
+    } else if (y >= 2) {  // first column
+        a = i - W;
+        b = i - 2 * W;
+    } else {  // pixel (0,1); W >= 2 because i >= 2
+        a = i - W;
+        b = i - W + 1;
+    }
+    int p = (int)pl[i], v1 = (int)pl[a], v2 = (int)pl[b];
+    int H = max(v1, v2), L = min(v1, v2);
+    PixelClass r;
+    r.ctx = (uint32_t)(H - L);
+    if (p < L) {
+        r.cls = CLS_BELOW;
+        r.val = (uint32_t)(L - p - 1);
+    } else if (p > H) {
+        r.cls = CLS_ABOVE;
+        r.val = (uint32_t)(p - H - 1);
+    } else {
+        r.cls = CLS_IN;
+        r.val = (uint32_t)(p - L);
+    }
+    return r;
+}
+
+// (x, y) of linear index i; advance() moves forward by `step` pixels without dividing again.
+struct Coord {
+    uint32_t x, y;
+    __device__ __forceinline__ void set(uint32_t i, uint32_t W) {
+        y = i / W;
+        x = i - y * W;
+    }
+    __device__ __forceinline__ void advance(uint32_t step, uint32_t W) {
+        x += step;
+        while (x >= W) {
+            x -= W;
+            y++;
+        }
+    }
+};
+
+}  // namespace felics

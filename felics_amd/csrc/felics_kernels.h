@@ -20,6 +20,14 @@ constexpr uint32_t PACK_TILE = PACK_THREADS * PACK_PER_THREAD;
 // LDS bit window of the pack stage: 2048 words = 8 KiB = 16 bits per pixel of a tile (more bits: more windows)
 constexpr uint32_t PACK_WIN_WORDS = 2048;
 
+// Sample type of a plane -> type of the per-group bit counts k_lengths hands to k_pack.
+// 8-bit samples (u8 gray, i16 Y/Co/Cg): a 16-pixel group is at most 16 * 513 bits.  16-bit samples
+// (u16 gray, i32 Y/Co/Cg): one code can be 2^17 bits long.
+template <typename T> struct GroupBits { using type = uint16_t; };
+template <> struct GroupBits<uint16_t> { using type = uint32_t; };
+template <> struct GroupBits<int32_t> { using type = uint32_t; };
+template <typename T> using group_bits_t = typename GroupBits<T>::type;
+
 struct Geometry {
     uint32_t W, H;
     uint32_t npix;              // W*H, pixels per plane
@@ -81,8 +89,8 @@ void launch_assign(hipStream_t s, const ET *sorted_e, const uint32_t *pix_of, ui
 // spine slice by slice.  tile_bitoff is relative to the plane; plane_base (zero for gray, set by
 // launch_finish_sizes for the later planes of an RGB image) makes it relative to the image stream.
 template <typename T>
-void launch_lengths(hipStream_t s, const T *planes, const uint8_t *k_map, uint16_t *group_bits, uint32_t *tile_bits,
-                    const Geometry &g, uint32_t t0, uint32_t t1);
+void launch_lengths(hipStream_t s, const T *planes, const uint8_t *k_map, group_bits_t<T> *group_bits,
+                    uint32_t *tile_bits, const Geometry &g, uint32_t t0, uint32_t t1);
 
 void launch_bitscan_slice(hipStream_t s, const uint32_t *tile_bits, uint64_t *tile_bitoff, uint64_t *plane_carry,
                           const Geometry &g, uint32_t t0, uint32_t t1);
@@ -101,9 +109,35 @@ void launch_zero_edges(hipStream_t s, uint8_t *out, const uint64_t *image_off, u
                        const Geometry &g, uint32_t t0, uint32_t t1);
 
 template <typename T>
-void launch_pack(hipStream_t s, const T *planes, const uint8_t *k_map, const uint16_t *group_bits,
+void launch_pack(hipStream_t s, const T *planes, const uint8_t *k_map, const group_bits_t<T> *group_bits,
                  const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint64_t *plane_base,
                  const uint64_t *image_off, uint64_t slot_stride, uint8_t *out, const Geometry &g, uint32_t t0,
                  uint32_t t1);
+
+// ---- 16-bit samples (felics_wide.hip): contexts 0..131070 and 15 Rice parameters (traits.rs:35-43).
+// The events of a batch are ordered by (plane, context) with a stable radix sort and every context's
+// chain is replayed by one wave; lengths / pack are the kernels above on u16 / i32 planes.
+constexpr uint32_t WIDE_CTX_BITS = 18;                          // contexts fit 17 bits; all-ones = "not an event"
+constexpr uint32_t WIDE_NO_EVENT = (1u << WIDE_CTX_BITS) - 1u;
+constexpr uint32_t WIDE_MAX_PLANES = 1u << (32 - WIDE_CTX_BITS);  // plane index above the context in the sort key
+
+void launch_rgb16_to_planes(hipStream_t s, const uint16_t *rgb, int32_t *planes, uint32_t npix, uint32_t nimg);
+
+// keys[g] = plane << 18 | context (or WIDE_NO_EVENT), vals[g] = g, e_of[g] = the value Rice-coded, for every
+// sample g = plane * npix + i of the batch
+template <typename T>
+void launch_wide_keys(hipStream_t s, const T *planes, uint32_t *keys, uint32_t *vals, uint32_t *e_of, const Geometry &g);
+
+// stable sort of (keys, vals) by key; *sorted_keys / *sorted_vals point into the a or b buffers afterwards
+size_t wide_sort_temp_bytes(size_t n, uint32_t key_bits);
+hipError_t wide_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a,
+                     uint32_t *vals_b, size_t n, uint32_t key_bits, uint32_t **sorted_keys, uint32_t **sorted_vals);
+
+// chain heads of the sorted keys -> heads[0 .. *nheads) (unordered); nheads must be zero beforehand
+void launch_wide_heads(hipStream_t s, const uint32_t *keys, uint32_t n, uint32_t *heads, uint32_t *nheads);
+
+// replay of the estimator along every chain: k_map[vals[j]] = k of event j
+void launch_wide_chains(hipStream_t s, const uint32_t *keys, const uint32_t *vals, const uint32_t *e_of, uint32_t n,
+                        const uint32_t *heads, const uint32_t *nheads, uint8_t *k_map);
 
 }  // namespace felics

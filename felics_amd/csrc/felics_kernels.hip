@@ -19,103 +19,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "felics_device.h"
 #include "felics_kernels.h"
 
 namespace felics {
-
-// ------------------------------------------------------------------------------------------
-// wave helpers
-// ------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
-
-__device__ __forceinline__ uint64_t lanemask_lt() {
-    return (1ull << lane_id()) - 1ull;
-}
-
-// Inclusive prefix sum over the 64 lanes of a wave, DPP only (no LDS):
-// 4 row_shr steps inside each row of 16, then row_bcast:15 / row_bcast:31 across rows.
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);  // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);  // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1,3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2,3
-    return v;
-}
-
-__device__ __forceinline__ uint32_t readlane(uint32_t v, uint32_t l) {
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
-}
-
-// number of set bits of m below this lane
-__device__ __forceinline__ uint32_t mbcnt(uint64_t m) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-// ------------------------------------------------------------------------------------------
-// per-pixel classification shared by hist / scatter / lengths / pack
-// ------------------------------------------------------------------------------------------
-
-enum : uint32_t { CLS_IN = 0, CLS_BELOW = 1, CLS_ABOVE = 2 };
-
-struct PixelClass {
-    uint32_t cls;  // CLS_*
-    uint32_t ctx;  // H - L
-    uint32_t val;  // p-L (in range), L-p-1 (below), p-H-1 (above)
-};
-
-// The two already-coded neighbours of pixel i = y*W + x, i >= 2 (misc.rs:6-24).
-template <typename T>
-__device__ __forceinline__ PixelClass classify(const T *__restrict__ pl, uint32_t i, uint32_t x,
-                                               uint32_t y, uint32_t W) {
-    uint32_t a, b;
-    if (x > 0 && y > 0) {
-        a = i - 1;
-        b = i - W;
-    } else if (y == 0) {  // first row, x >= 2 because i >= 2
-        a = i - 1;
-        b = i - 2;
-    } else if (y >= 2) {  // first column
-        a = i - W;
-        b = i - 2 * W;
-    } else {  // pixel (0,1); W >= 2 because i >= 2
-        a = i - W;
-        b = i - W + 1;
-    }
-    int p = (int)pl[i], v1 = (int)pl[a], v2 = (int)pl[b];
-    int H = max(v1, v2), L = min(v1, v2);
-    PixelClass r;
-    r.ctx = (uint32_t)(H - L);
-    if (p < L) {
-        r.cls = CLS_BELOW;
-        r.val = (uint32_t)(L - p - 1);
-    } else if (p > H) {
-        r.cls = CLS_ABOVE;
-        r.val = (uint32_t)(p - H - 1);
-    } else {
-        r.cls = CLS_IN;
-        r.val = (uint32_t)(p - L);
-    }
-    return r;
-}
-
-// (x, y) of linear index i; advance() moves forward by `step` pixels without dividing again.
-struct Coord {
-    uint32_t x, y;
-    __device__ __forceinline__ void set(uint32_t i, uint32_t W) {
-        y = i / W;
-        x = i - y * W;
-    }
-    __device__ __forceinline__ void advance(uint32_t step, uint32_t W) {
-        x += step;
-        while (x >= W) {
-            x -= W;
-            y++;
-        }
-    }
-};
 
 // ------------------------------------------------------------------------------------------
 // planes: interleaved RGB8 -> three int16 planes Y, Co, Cg (color_transform.rs:11-17).
@@ -708,6 +615,10 @@ __device__ __forceinline__ int sample_at(const uint32_t *w, uint32_t j, uint8_t)
 __device__ __forceinline__ int sample_at(const uint32_t *w, uint32_t j, int16_t) {
     return (int)(int16_t)(w[j >> 1] >> (16u * (j & 1u)));
 }
+__device__ __forceinline__ int sample_at(const uint32_t *w, uint32_t j, uint16_t) {
+    return (int)((w[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu);
+}
+__device__ __forceinline__ int sample_at(const uint32_t *w, uint32_t j, int32_t) { return (int)w[j]; }
 
 // Calls raw(i, value) for pixels 0 and 1 of the plane (stored as 32-bit values,
 // compression.rs:105-106) and f(pc, k) for every other pixel of this thread's group, in raster order.
@@ -789,13 +700,14 @@ __device__ __forceinline__ void walk_group(const TileLDS<T> &t, const T *__restr
 }
 
 // ------------------------------------------------------------------------------------------
-// lengths: bits of every 16-pixel group (group_bits, u16) and of every tile (tile_bits).
+// lengths: bits of every 16-pixel group (group_bits: u16 for 8-bit samples, u32 for 16-bit ones,
+// whose codes reach 2^17 bits) and of every tile (tile_bits).
 // Plane 0 of an image also carries the 112 header bits.
 // ------------------------------------------------------------------------------------------
 
 template <typename T>
 __global__ __launch_bounds__(PACK_THREADS) void k_lengths(const T *__restrict__ planes, const uint8_t *__restrict__ k_map,
-                                                          uint16_t *__restrict__ group_bits,
+                                                          group_bits_t<T> *__restrict__ group_bits,
                                                           uint32_t *__restrict__ tile_bits, uint32_t W, uint32_t npix,
                                                           uint32_t ntiles, uint32_t planes_per_image,
                                                           uint32_t tile_begin) {
@@ -813,7 +725,7 @@ __global__ __launch_bounds__(PACK_THREADS) void k_lengths(const T *__restrict__ 
                [&](const PixelClass &pc, uint32_t k) { bits += code_length(pc, k); });
     if (npix == 1 && first == 0) bits += 32;  // 1x1: second raw value is a literal 0 (compression.rs:99-103)
     if (tile == 0 && threadIdx.x == 0 && (plane % planes_per_image) == 0) bits += 8 * 14;  // header
-    group_bits[((uint64_t)plane * ntiles + tile) * PACK_THREADS + threadIdx.x] = (uint16_t)bits;
+    group_bits[((uint64_t)plane * ntiles + tile) * PACK_THREADS + threadIdx.x] = (group_bits_t<T>)bits;
     const uint32_t inc = wave_incl_scan(bits);
     if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
     __syncthreads();
@@ -967,9 +879,19 @@ struct LaneBits {
         }
     }
     __device__ __forceinline__ void put_ones(uint32_t q) {  // write_unary0's run of ones
-        while (q >= 32) {
+        if (q >= 32) {
             put(0xFFFFFFFFu, 32);
             q -= 32;
+            // Every further whole word of the run is all ones and leaves acc / fill as they are: only the
+            // words inside the window are touched (16-bit samples: a run can be 2^17 bits long).
+            const uint64_t n = q >> 5;
+            if (n) {
+                const uint64_t lo = cur_word > win_word0 ? cur_word : win_word0;
+                const uint64_t hi = cur_word + n < win_word0 + PACK_WIN_WORDS ? cur_word + n : win_word0 + PACK_WIN_WORDS;
+                for (uint64_t w = lo; w < hi; w++) atomicOr(&win[w - win_word0], 0xFFFFFFFFu);
+                cur_word += n;
+                q &= 31u;
+            }
         }
         if (q) put((1u << q) - 1u, q);
     }
@@ -1000,7 +922,7 @@ __device__ __forceinline__ void put_pixel(LaneBits &bw, const PixelClass &pc, ui
 
 template <typename T>
 __global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ planes, const uint8_t *__restrict__ k_map,
-                                                       const uint16_t *__restrict__ group_bits,
+                                                       const group_bits_t<T> *__restrict__ group_bits,
                                                        const uint64_t *__restrict__ tile_bitoff,
                                                        const uint32_t *__restrict__ tile_bits,
                                                        const uint64_t *__restrict__ plane_base, Placement place,
@@ -1164,8 +1086,8 @@ template void launch_assign<uint16_t>(hipStream_t, const uint16_t *, const uint3
                                       const Geometry &);
 
 template <typename T>
-void launch_lengths(hipStream_t s, const T *planes, const uint8_t *k_map, uint16_t *group_bits, uint32_t *tile_bits,
-                    const Geometry &g, uint32_t t0, uint32_t t1) {
+void launch_lengths(hipStream_t s, const T *planes, const uint8_t *k_map, group_bits_t<T> *group_bits,
+                    uint32_t *tile_bits, const Geometry &g, uint32_t t0, uint32_t t1) {
     if (t1 <= t0) return;
     hipLaunchKernelGGL((k_lengths<T>), dim3(t1 - t0, g.nplanes), dim3(PACK_THREADS), 0, s, planes, k_map, group_bits,
                        tile_bits, g.W, g.npix, g.pack_tiles, g.planes_per_image, t0);
@@ -1173,6 +1095,10 @@ void launch_lengths(hipStream_t s, const T *planes, const uint8_t *k_map, uint16
 template void launch_lengths<uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, uint16_t *, uint32_t *,
                                       const Geometry &, uint32_t, uint32_t);
 template void launch_lengths<int16_t>(hipStream_t, const int16_t *, const uint8_t *, uint16_t *, uint32_t *,
+                                      const Geometry &, uint32_t, uint32_t);
+template void launch_lengths<uint16_t>(hipStream_t, const uint16_t *, const uint8_t *, uint32_t *, uint32_t *,
+                                       const Geometry &, uint32_t, uint32_t);
+template void launch_lengths<int32_t>(hipStream_t, const int32_t *, const uint8_t *, uint32_t *, uint32_t *,
                                       const Geometry &, uint32_t, uint32_t);
 
 void launch_bitscan_slice(hipStream_t s, const uint32_t *tile_bits, uint64_t *tile_bitoff, uint64_t *plane_carry,
@@ -1206,7 +1132,7 @@ void launch_zero_edges(hipStream_t s, uint8_t *out, const uint64_t *image_off, u
 }
 
 template <typename T>
-void launch_pack(hipStream_t s, const T *planes, const uint8_t *k_map, const uint16_t *group_bits,
+void launch_pack(hipStream_t s, const T *planes, const uint8_t *k_map, const group_bits_t<T> *group_bits,
                  const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint64_t *plane_base,
                  const uint64_t *image_off, uint64_t slot_stride, uint8_t *out, const Geometry &g, uint32_t t0,
                  uint32_t t1) {
@@ -1220,6 +1146,12 @@ template void launch_pack<uint8_t>(hipStream_t, const uint8_t *, const uint8_t *
                                    const uint32_t *, const uint64_t *, const uint64_t *, uint64_t, uint8_t *,
                                    const Geometry &, uint32_t, uint32_t);
 template void launch_pack<int16_t>(hipStream_t, const int16_t *, const uint8_t *, const uint16_t *, const uint64_t *,
+                                   const uint32_t *, const uint64_t *, const uint64_t *, uint64_t, uint8_t *,
+                                   const Geometry &, uint32_t, uint32_t);
+template void launch_pack<uint16_t>(hipStream_t, const uint16_t *, const uint8_t *, const uint32_t *, const uint64_t *,
+                                    const uint32_t *, const uint64_t *, const uint64_t *, uint64_t, uint8_t *,
+                                    const Geometry &, uint32_t, uint32_t);
+template void launch_pack<int32_t>(hipStream_t, const int32_t *, const uint8_t *, const uint32_t *, const uint64_t *,
                                    const uint32_t *, const uint64_t *, const uint64_t *, uint64_t, uint8_t *,
                                    const Geometry &, uint32_t, uint32_t);
 

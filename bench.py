@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=64, help="frames per rank per step")
     ap.add_argument("--kind", default="S1", choices=["S1", "S2", "S3"])
     ap.add_argument("--rgb", action="store_true", help="RGB8 frames (config 4/5) instead of gray8")
+    ap.add_argument("--depth16", action="store_true", help="16-bit grayscale frames (side measurement, not the headline)")
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
@@ -102,18 +103,28 @@ def main():
     npix = W * H
     # this rank's shard of the job (weak scaling: F frames per rank), generated straight into HBM
     first_frame, _ = fdist.shard_range(F * world, rank, world)
-    frames = torch.empty((F, H, W, channels) if args.rgb else (F, H, W), dtype=torch.uint8, device=dev)
-    for i in range(F):
-        f = first_frame + i
-        frames[i] = synth_torch.rgb8(W, H, f, device=dev) if args.rgb else synth_torch.gray8(W, H, f, args.kind, device=dev)
-    d_out = torch.empty(int(F * npix * channels * 1.25) + (1 << 20), dtype=torch.uint8, device=dev)
+    sample_bytes = 2 if args.depth16 else 1
+    if args.depth16:
+        if args.rgb:
+            raise SystemExit("--depth16 is grayscale only")
+        from felics_amd import synth
+
+        base = [torch.from_numpy(synth.gray16(W, H, first_frame + i).view(np.int16)) for i in range(min(F, 4))]
+        frames = torch.stack([base[i % len(base)] for i in range(F)]).to(dev)  # int16 storage of the u16 samples
+    else:
+        frames = torch.empty((F, H, W, channels) if args.rgb else (F, H, W), dtype=torch.uint8, device=dev)
+        for i in range(F):
+            f = first_frame + i
+            frames[i] = synth_torch.rgb8(W, H, f, device=dev) if args.rgb else synth_torch.gray8(W, H, f, args.kind, device=dev)
+    d_out = torch.empty(int(F * npix * channels * sample_bytes * 1.25) + (1 << 20), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
     enc = felics_amd.Encoder(local)
     color = 1 if args.rgb else 0
 
     def step():
-        return enc.compress_batch_device(frames.data_ptr(), F, W, H, color, 0, d_out.data_ptr(), d_out.numel())
+        return enc.compress_batch_device(frames.data_ptr(), F, W, H, color, 1 if args.depth16 else 0, d_out.data_ptr(),
+                                         d_out.numel())
 
     # ---- parity first: byte-compare a few streams with the oracle, checksum the rest ----
     offs, lens = step()
@@ -123,7 +134,7 @@ def main():
     oracle = oracle_lib.load()
     checked = 0
     for i in range(min(args.check_frames, F)):
-        want = oracle.compress(frames[i].cpu().numpy())
+        want = oracle.compress(frames[i].cpu().numpy().view(np.uint16) if args.depth16 else frames[i].cpu().numpy())
         got = host[int(offs[i]): int(offs[i] + lens[i])].tobytes()
         if got != want:
             raise SystemExit("rank %d frame %d: GPU stream differs from the oracle" % (rank, i))
@@ -159,7 +170,7 @@ def main():
         value = world * F * npix * steps / elapsed / 1e6  # MPix/s, whole job
         stage_ms = {k: v / steps for k, v in stage_acc.items()}
         dom = max(stage_ms, key=stage_ms.get) if stage_ms else None
-        alg_bytes = F * npix * channels  # 1 B/pixel/channel read, SURVEY.md §8(d)
+        alg_bytes = F * npix * channels * sample_bytes  # 1 B/pixel/channel read (2 for 16-bit), SURVEY.md §8(d)
         # A step launches most kernels once per slice of the images; stage_ms[k] is the sum of the
         # durations of kernel k's launches in one step (HIP events on the stream each launch runs on).
         launches = max(1, enc.stage_launches().get(dom, 1)) if dom else 1
@@ -170,7 +181,7 @@ def main():
             achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC FETCH_SIZE + WRITE_SIZE of this command
-            if os.path.exists(tpath) and not args.rgb and args.kind == "S1" and F == 64 and (W, H) == (W4K, H4K):
+            if os.path.exists(tpath) and not args.rgb and not args.depth16 and args.kind == "S1" and F == 64 and (W, H) == (W4K, H4K):
                 traffic = json.load(open(tpath)).get("k_" + dom, {}).get("hbm_bytes_per_step")
                 traffic = int(traffic / launches) if traffic else None
             roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -180,7 +191,8 @@ def main():
         pipeline_gbs = alg_bytes / (ms_per_step * 1e-3) / 1e9
         cpu1 = cpum = None
         if args.cpu_seconds > 0:
-            sample = [frames[i].cpu().numpy() for i in range(min(F, 16))]
+            sample = [frames[i].cpu().numpy().view(np.uint16) if args.depth16 else frames[i].cpu().numpy()
+                      for i in range(min(F, 16))]
             cpu1, cpum = cpu_baseline(sample, args.cpu_seconds)
             cpu1["value"] = round(cpu1["value"], 2)
             cpum["value"] = round(cpum["value"], 2)
@@ -188,9 +200,10 @@ def main():
             "metric": "encode MPix/s on 4K 8-bit grayscale batch (bit-exact); % HBM-read roofline",
             "value": round(value, 1), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "batch of %d synthetic %s %dx%d 8-bit %s frames per GPU, resident in HBM"
-                                   % (F, "S1-RGB" if args.rgb else args.kind, W, H, "RGB" if args.rgb else "grayscale"),
+            "dtype": "u16" if args.depth16 else "u8", "data": "synthetic",
+            "config": {"workload": "batch of %d synthetic %s %dx%d %d-bit %s frames per GPU, resident in HBM"
+                                   % (F, "S1-RGB" if args.rgb else args.kind, W, H, 16 if args.depth16 else 8,
+                                      "RGB" if args.rgb else "grayscale"),
                        "frames_per_gpu": F, "width": W, "height": H, "channels": channels,
                        "sharding": "frames split across ranks, no collective"},
             "roofline": roofline,

@@ -50,6 +50,16 @@ struct PixelClass {
     uint32_t val;  // p-L (in range), L-p-1 (below), p-H-1 (above)
 };
 
+// Pixel p against its two neighbours' values (compression.rs:124-145).
+__device__ __forceinline__ PixelClass classify_values(int p, int v1, int v2) {
+    const int H = max(v1, v2), L = min(v1, v2);
+    PixelClass r;
+    r.ctx = (uint32_t)(H - L);
+    r.cls = p < L ? CLS_BELOW : (p > H ? CLS_ABOVE : CLS_IN);
+    r.val = p < L ? (uint32_t)(L - p - 1) : (p > H ? (uint32_t)(p - H - 1) : (uint32_t)(p - L));
+    return r;
+}
+
 // The two already-coded neighbours of pixel i = y*W + x, i >= 2 (misc.rs:6-24).
 template <typename T>
 __device__ __forceinline__ PixelClass classify(const T *__restrict__ pl, uint32_t i, uint32_t x,
@@ -68,21 +78,13 @@ __device__ __forceinline__ PixelClass classify(const T *__restrict__ pl, uint32_
         a = i - W;
         b = i - W + 1;
     }
-    int p = (int)pl[i], v1 = (int)pl[a], v2 = (int)pl[b];
-    int H = max(v1, v2), L = min(v1, v2);
-    PixelClass r;
-    r.ctx = (uint32_t)(H - L);
-    if (p < L) {
-        r.cls = CLS_BELOW;
-        r.val = (uint32_t)(L - p - 1);
-    } else if (p > H) {
-        r.cls = CLS_ABOVE;
-        r.val = (uint32_t)(p - H - 1);
-    } else {
-        r.cls = CLS_IN;
-        r.val = (uint32_t)(p - L);
-    }
-    return r;
+    return classify_values((int)pl[i], (int)pl[a], (int)pl[b]);
+}
+
+// Interior pixel (x > 0, y > 0): left and above, no case analysis.
+template <typename T>
+__device__ __forceinline__ PixelClass classify_interior(const T *__restrict__ pl, uint32_t i, uint32_t W) {
+    return classify_values((int)pl[i], (int)pl[i - 1], (int)pl[i - W]);
 }
 
 // (x, y) of linear index i; advance() moves forward by `step` pixels without dividing again.

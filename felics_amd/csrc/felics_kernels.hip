@@ -67,26 +67,45 @@ __global__ __launch_bounds__(256) void k_hist(const T *__restrict__ planes, uint
         const T *pl = planes + (uint64_t)plane * npix;
         const uint32_t begin = tile * SORT_TILE;
         const uint32_t end = min(begin + SORT_TILE, npix);
-        // Four rows per trip: the twelve loads of a trip are in flight together (the kernel is bound by
-        // their latency, not by the atomics).
-        Coord xy;
-        xy.set(begin + lane, W);
-        for (uint32_t i0 = begin + lane; i0 < end; i0 += 256) {
+        // Four rows per trip: the twelve loads of a trip are in flight together.  (x0, y0) is the
+        // trip's first pixel, tracked in scalar registers; a trip whose 256 pixels lie inside one image
+        // row with x > 0, y > 0 -- nearly all of them -- takes the neighbour rule's interior case
+        // without any per-pixel case analysis.
+        uint32_t y0 = begin / W, x0 = begin - y0 * W;
+        for (uint32_t r0 = begin; r0 < end; r0 += 256) {
             PixelClass pc[4];
             bool ev[4];
+            const bool interior = y0 > 0 && x0 > 0 && x0 + 256 <= W && r0 + 256 <= end;
+            if (interior) {
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t i = i0 + u * 64;
-                ev[u] = false;
-                if (i < end && i >= 2) {
-                    pc[u] = classify(pl, i, xy.x, xy.y, W);
+                for (uint32_t u = 0; u < 4; u++) {
+                    pc[u] = classify_interior(pl, r0 + u * 64 + lane, W);
                     ev[u] = pc[u].cls != CLS_IN;
                 }
-                xy.advance(64, W);
+            } else {
+                Coord xy;
+                xy.x = x0;
+                xy.y = y0;
+                xy.advance(lane, W);
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {
+                    const uint32_t i = r0 + u * 64 + lane;
+                    ev[u] = false;
+                    if (i < end && i >= 2) {
+                        pc[u] = classify(pl, i, xy.x, xy.y, W);
+                        ev[u] = pc[u].cls != CLS_IN;
+                    }
+                    xy.advance(64, W);
+                }
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++)
                 if (ev[u]) atomicAdd(&hist[wave][pc[u].ctx], 1u);
+            x0 += 256;
+            while (x0 >= W) {
+                x0 -= W;
+                y0++;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t *dst = counts + ((uint64_t)plane * ntiles + tile) * NCTX;
@@ -197,70 +216,88 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
     const uint32_t plane_first = plane * npix;
     const uint32_t begin = tile * SORT_TILE;
     const uint32_t end = min(begin + SORT_TILE, npix);
-    Coord xy;
-    xy.set(begin + lane, W);
-    for (uint32_t row = begin; row < end; row += 64) {
-        const uint32_t i = row + lane;
-        bool ev = false;
-        uint32_t c = 0, e = 0;
-        if (i < end && i >= 2) {
-            PixelClass pc = classify(pl, i, xy.x, xy.y, W);
-            ev = pc.cls != CLS_IN;
-            c = pc.ctx;
-            e = pc.val;
-        }
-        xy.advance(64, W);
-        // Rank the lanes that share a context with ballots only (no memory in the loop): every event
-        // lane learns how many earlier lanes of this row hold its context (rank) and how many lanes
-        // hold it in all (group).  Contexts 0..HOT-1 carry most events of real images: they are ranked
-        // by HOT independent ballots; whatever is left goes through the one-context-per-trip loop.
-        uint32_t rank = 0, group = 0;
-        constexpr uint32_t HOT = 8;
-        {
-            // every lane picks the ballot of its own context out of the HOT ballots (two selects per
-            // context), then ranks itself against that mask once
-            uint32_t sel_lo = 0, sel_hi = 0;
+    // Four rows per trip: their twelve loads are in flight together (one row at a time the kernel waits
+    // for memory once per row); the rows are then ranked and stored one after the other.  (x0, y0) is the
+    // trip's first pixel (scalar); trips inside one image row with x > 0, y > 0 skip the neighbour rule's
+    // case analysis.
+    uint32_t y0 = begin / W, x0 = begin - y0 * W;
+    for (uint32_t row0 = begin; row0 < end; row0 += 256) {
+        bool evs[4];
+        uint32_t cs[4], es[4];
+        const bool interior = y0 > 0 && x0 > 0 && x0 + 256 <= W && row0 + 256 <= end;
+        if (interior) {
 #pragma unroll
-            for (uint32_t t = 0; t < HOT; t++) {
-                const bool is_t = c == t;
-                const uint64_t m = __ballot(ev && is_t);
-                sel_lo = is_t ? (uint32_t)m : sel_lo;
-                sel_hi = is_t ? (uint32_t)(m >> 32) : sel_hi;
+            for (uint32_t u = 0; u < 4; u++) {
+                const PixelClass pc = classify_interior(pl, row0 + u * 64 + lane, W);
+                evs[u] = pc.cls != CLS_IN;
+                cs[u] = pc.ctx;
+                es[u] = pc.val;
             }
-            if (ev && c < HOT) {
-                rank = __builtin_amdgcn_mbcnt_hi(sel_hi, __builtin_amdgcn_mbcnt_lo(sel_lo, 0u));
-                group = (uint32_t)__popc(sel_lo) + (uint32_t)__popc(sel_hi);
+        } else {
+            Coord xy;
+            xy.x = x0;
+            xy.y = y0;
+            xy.advance(lane, W);
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t i = row0 + u * 64 + lane;
+                evs[u] = false;
+                cs[u] = 0;
+                es[u] = 0;
+                if (i < end && i >= 2) {
+                    const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
+                    evs[u] = pc.cls != CLS_IN;
+                    cs[u] = pc.ctx;
+                    es[u] = pc.val;
+                }
+                xy.advance(64, W);
             }
         }
-        // Whatever is left (contexts >= HOT) is matched bit by bit: after the nine ballots below every
-        // lane holds the mask of the lanes whose context equals its own -- a fixed cost, however many
-        // different contexts the row holds (busy images have 10-40 per row).
-        const bool rest = ev && c >= HOT;
-        const uint64_t rest_mask = __ballot(rest);
-        if (rest_mask != 0) {
-            uint32_t m_lo = (uint32_t)rest_mask, m_hi = (uint32_t)(rest_mask >> 32);
+        x0 += 256;
+        while (x0 >= W) {
+            x0 -= W;
+            y0++;
+        }
 #pragma unroll
-            for (uint32_t b = 0; b < 9; b++) {  // contexts are < 512
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t i = row0 + u * 64 + lane;
+            const bool ev = evs[u];
+            const uint32_t c = cs[u], e = es[u];
+            // Rank the lanes that share a context with ballots only (no memory in the loop): every event
+            // lane learns how many earlier lanes of this row hold its context (rank) and how many lanes
+            // hold it in all (group).  Contexts are matched bit by bit: after one ballot per context bit
+            // every lane holds the mask of the lanes whose context equals its own -- a fixed cost, however
+            // many different contexts the row holds (busy images have 10-40 per row).  Most rows only hold
+            // contexts below 32 and get away with five of the nine bits.
+            uint32_t rank = 0, group = 0;
+            const uint64_t ev_mask = __ballot(ev);
+            if (ev_mask == 0) continue;
+            uint32_t m_lo = (uint32_t)ev_mask, m_hi = (uint32_t)(ev_mask >> 32);
+            auto match_bit = [&](uint32_t b) {
                 const uint32_t t = (uint32_t)((int32_t)(c << (31 - b)) >> 31);  // all ones if bit b of c is set
-                const uint64_t bb = __ballot(rest && t != 0);
+                const uint64_t bb = __ballot(ev && t != 0);
                 m_lo &= ~((uint32_t)bb ^ t);
                 m_hi &= ~((uint32_t)(bb >> 32) ^ t);
+            };
+#pragma unroll
+            for (uint32_t b = 0; b < 5; b++) match_bit(b);
+            if (__ballot(ev && c >= 32u) != 0) {  // contexts are < 512
+#pragma unroll
+                for (uint32_t b = 5; b < 9; b++) match_bit(b);
             }
-            if (rest) {
-                rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
-                group = (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);
+            rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+            group = (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);
+            const bool leader = ev && rank == 0;  // first lane of its context in this row
+            // one LDS read per lane (same context -> same address -> broadcast), one write per leader
+            uint32_t dest = 0;
+            if (ev) dest = run[c] + rank;
+            __builtin_amdgcn_wave_barrier();
+            if (leader) run[c] = dest + group;  // the leader has rank 0: dest is the context's running offset
+            __builtin_amdgcn_wave_barrier();
+            if (ev) {
+                sorted_e[dest] = (ET)e;
+                pix_of[dest] = plane_first + i;
             }
-        }
-        const bool leader = ev && rank == 0;  // first lane of its context in this row
-        // one LDS read per lane (same context -> same address -> broadcast), one write per leader
-        uint32_t dest = 0;
-        if (ev) dest = run[c] + rank;
-        __builtin_amdgcn_wave_barrier();
-        if (leader) run[c] = dest + group;  // the leader has rank 0: dest is the context's running offset
-        __builtin_amdgcn_wave_barrier();
-        if (ev) {
-            sorted_e[dest] = (ET)e;
-            pix_of[dest] = plane_first + i;
         }
     }
 }
@@ -345,6 +382,9 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
     uint4 *states = reinterpret_cast<uint4 *>(block_state) + (uint64_t)(base >> 6) * 2;
     uint32_t *tags = block_tag + (base >> 6);  // per block: (epoch, slice) of the launch that resolved it
     uint32_t Sv = l7 < 6 ? prog[1 + l7] : 0u;
+    // The state must have landed before the walk starts: a load still pending on entry makes the compiler
+    // wait for *all* memory operations inside the walk loop, i.e. for the next batch's prefetch as well.
+    asm volatile("; state in %0" : "+v"(Sv));
     if (first_block < nblocks) {
     __builtin_amdgcn_s_setprio(3);  // a chain is one long dependent instruction stream: never make it wait for issue
 
@@ -457,13 +497,28 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
 // same values, so nothing read here is in flux.  Waves scan 64 tags / 64 list entries at a time.
 constexpr uint32_t TAG_SLICE_BITS = 5;  // tag = epoch << 4 | slice
 
-__device__ __forceinline__ void assign_block(const uint4 *__restrict__ st, const uint32_t gb, const uint32_t valid,
-                                             const uint32_t e, const uint32_t pix, uint8_t *__restrict__ k_map) {
+// what a wave needs to serve one block: the block's record and, per lane, its event and its pixel
+struct BlockIn {
+    uint4 sa, sb;
+    uint32_t e, pix;
+};
+
+template <typename ET>
+__device__ __forceinline__ BlockIn load_block(const uint4 *__restrict__ st, const ET *__restrict__ sorted_e,
+                                              const uint32_t *__restrict__ pix_of, const uint32_t gb) {
+    BlockIn in;
+    in.sa = st[(uint64_t)gb * 2];
+    in.sb = st[(uint64_t)gb * 2 + 1];
+    in.e = (uint32_t)sorted_e[(uint64_t)gb * 64 + lane_id()];
+    in.pix = pix_of[(uint64_t)gb * 64 + lane_id()];
+    return in;
+}
+
+__device__ __forceinline__ void assign_block(const BlockIn &in, const uint32_t valid, uint8_t *__restrict__ k_map) {
     const uint32_t lane = lane_id();
-    const uint4 sa = st[(uint64_t)gb * 2], sb = st[(uint64_t)gb * 2 + 1];
-    uint32_t S0 = sa.x, S1 = sa.y, S2 = sa.z, S3 = sa.w, S4 = sb.x, S5 = sb.y;
+    uint32_t S0 = in.sa.x, S1 = in.sa.y, S2 = in.sa.z, S3 = in.sa.w, S4 = in.sb.x, S5 = in.sb.y;
     uint32_t l01, l23, l45;
-    packed_lengths(e, l01, l23, l45);
+    packed_lengths(in.e, l01, l23, l45);
     const uint32_t p01 = wave_incl_scan(l01), p23 = wave_incl_scan(l23), p45 = wave_incl_scan(l45);
     const uint32_t P0 = p01 & 0xFFFFu, P1 = p01 >> 16, P2 = p23 & 0xFFFFu, P3 = p23 >> 16;
     const uint32_t P4 = p45 & 0xFFFFu, P5 = p45 >> 16;
@@ -493,9 +548,12 @@ __device__ __forceinline__ void assign_block(const uint4 *__restrict__ st, const
         if (lo >= 64) break;
     }
     // lanes past the block's events in place hold no event yet; padding slots belong to no pixel
-    if (lane < valid && pix != 0xFFFFFFFFu) k_map[pix] = (uint8_t)kk;
+    if (lane < valid && in.pix != 0xFFFFFFFFu) k_map[in.pix] = (uint8_t)kk;
 }
 
+// Tags are dealt to the waves one by one (tag g belongs to wave g % nwaves): the blocks a spine launch
+// resolved are long runs of consecutive blocks of the long chains, and this way a run is shared by as
+// many waves as it has blocks.  While a block is computed the next block's loads are already in flight.
 template <typename ET>
 __global__ __launch_bounds__(256) void k_assign(const ET *__restrict__ sorted_e, const uint32_t *__restrict__ block_state,
                                                 const uint32_t *__restrict__ pix_of, uint8_t *__restrict__ k_map,
@@ -508,25 +566,39 @@ __global__ __launch_bounds__(256) void k_assign(const ET *__restrict__ sorted_e,
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint4 *st = reinterpret_cast<const uint4 *>(block_state);
     // blocks resolved by this slice's spine launch
-    for (uint32_t g0 = wave * 64; g0 < nblocks; g0 += nwaves * 64) {
-        const uint32_t mine = g0 + lane;
+    for (uint32_t g0 = wave; g0 < nblocks; g0 += nwaves * 64) {
+        const uint64_t mine = (uint64_t)g0 + (uint64_t)lane * nwaves;
         uint64_t todo = __ballot(mine < nblocks && block_tag[mine] == stamp);
-        while (todo) {
-            const uint32_t gb = g0 + (uint32_t)__ffsll((long long)todo) - 1u;
-            todo &= todo - 1;
-            assign_block(st, gb, 64u, (uint32_t)sorted_e[(uint64_t)gb * 64 + lane], pix_of[(uint64_t)gb * 64 + lane], k_map);
+        if (todo == 0) continue;
+        uint32_t gb = g0 + ((uint32_t)__ffsll((long long)todo) - 1u) * nwaves;
+        todo &= todo - 1;
+        BlockIn cur = load_block<ET>(st, sorted_e, pix_of, gb);
+        while (true) {
+            const bool more = todo != 0;
+            BlockIn nxt = cur;
+            if (more) {
+                gb = g0 + ((uint32_t)__ffsll((long long)todo) - 1u) * nwaves;
+                todo &= todo - 1;
+                nxt = load_block<ET>(st, sorted_e, pix_of, gb);
+            }
+            assign_block(cur, 64u, k_map);
+            if (!more) break;
+            cur = nxt;
         }
     }
-    // per chain: the block with events in place that is not full yet
-    for (uint32_t c0 = wave * 64; c0 < nchains; c0 += nwaves * 64) {
+    // per chain: the block with events in place that is not full yet (entries dealt like the tags: the
+    // chains that have one are neighbours in the list)
+    for (uint32_t c0 = wave; c0 < nchains; c0 += nwaves * 64) {
+        const uint64_t mine = (uint64_t)c0 + (uint64_t)lane * nwaves;
         uint2 entry = make_uint2(0u, 0u);
-        if (c0 + lane < nchains) entry = partial[c0 + lane];
+        if (mine < nchains) entry = partial[mine];
         uint64_t todo = __ballot(entry.y != 0);
         while (todo) {
             const uint32_t b = (uint32_t)__ffsll((long long)todo) - 1u;
             todo &= todo - 1;
             const uint32_t gb = readlane(entry.x, b), valid = readlane(entry.y, b);
-            assign_block(st, gb, valid, (uint32_t)sorted_e[(uint64_t)gb * 64 + lane], pix_of[(uint64_t)gb * 64 + lane], k_map);
+            const BlockIn in = load_block<ET>(st, sorted_e, pix_of, gb);
+            assign_block(in, valid, k_map);
         }
     }
 }

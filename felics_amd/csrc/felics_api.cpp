@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -52,7 +53,7 @@ struct Lane {
     uint64_t *h_sizes = nullptr;      // pinned: image_bytes[n] followed by image_off[n + 1]
     size_t h_sizes_cap = 0;
     DevBuf planes, counts, chain_len, chain_base, chain_prog, scalars, sorted_e, pix_of, k_map, block_state, group_bits,
-        tile_bits, tile_bitoff, plane_sums, image_bytes, image_off, partial, block_tag;
+        tile_bits, tile_bitoff, plane_sums, image_bytes, image_off, partial, block_tag, status, edge_first, edge_last;
     DevBuf wkeys[2], wvals[2], e_of, heads, sort_temp;  // 16-bit samples: sort records, Rice operands, chain heads
     uint32_t epoch = 0;               // sub-batches this lane has run: block tags are (epoch, slice)
     // the sub-batch in flight
@@ -222,6 +223,9 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     if ((rc = reserve(ctx, l.plane_sums, (size_t)g.nplanes * 16)) != 0) return rc;  // carry[nplanes], base[nplanes]
     if ((rc = reserve(ctx, l.image_bytes, (size_t)g.nimages * 8)) != 0) return rc;
     if ((rc = reserve(ctx, l.image_off, (size_t)(g.nimages + 1) * 8)) != 0) return rc;
+    if ((rc = reserve_zeroed(ctx, l.status, (size_t)g.nplanes * g.pack_tiles * 8)) != 0) return rc;
+    if ((rc = reserve(ctx, l.edge_first, (size_t)g.nplanes * g.pack_tiles * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.edge_last, (size_t)g.nplanes * g.pack_tiles * 4)) != 0) return rc;
     const size_t hs = (size_t)g.nimages * 2 + 1;
     if (hs > l.h_sizes_cap) {
         if (l.h_sizes) HIP_TRY(ctx, hipHostFree(l.h_sizes));
@@ -245,12 +249,16 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         l.epoch = 1;
     }
     const uint32_t epoch = l.epoch;
+    if ((epoch & 0x3FFFFu) == 0) HIP_TRY(ctx, hipMemset(l.status.p, 0, l.status.cap));  // look-back tags: 18 epoch bits
+    // gray frames with fixed slots: code lengths, tile offsets and packing in one kernel per slice
     const bool pack_by_slice = slot_stride != 0 && g.planes_per_image == 1;
+    const bool fused = pack_by_slice && std::is_same<T, uint8_t>::value && !getenv("FELICS_TWO_PASS");
+    uint32_t *d_error = (uint32_t *)l.scalars.p + 8;  // look-back watchdog of the single-pass pack
 
     // ---- front stream
     if (ctx->poison) {  // FELICS_POISON: every intermediate buffer starts as garbage, as on a fresh context
         DevBuf *bufs[] = {&l.counts, &l.chain_len, &l.chain_base, &l.sorted_e, &l.pix_of, &l.k_map, &l.block_state,
-                          &l.group_bits, &l.tile_bits, &l.tile_bitoff};
+                          &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.edge_first, &l.edge_last};
         for (DevBuf *b : bufs) HIP_TRY(ctx, hipMemsetAsync(b->p, 0xA5, b->cap, f));
     }
     {
@@ -301,10 +309,30 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     }
     // ---- tail stream: code lengths, bit offsets and (with fixed slots) the packed bits of each slice's tiles
     HIP_TRY(ctx, hipMemsetAsync(plane_carry, 0, (size_t)g.nplanes * 16, tl));
+    HIP_TRY(ctx, hipMemsetAsync(d_error, 0, 4, tl));
     for (int q = 0; q < SLICES; q++) {
         HIP_TRY(ctx, hipStreamWaitEvent(tl, l.assign_done[q], 0));
         const bool last = q + 1 == SLICES;
         if (bounds[q + 1] == bounds[q] && !last) continue;
+        if constexpr (std::is_same<T, uint8_t>::value) {
+            if (fused) {
+                {
+                    StageTimer t(ctx, l, ST_PACK, tl);
+                    launch_pack_fused<T>(tl, d_planes, (const uint8_t *)l.k_map.p, (uint64_t *)l.status.p,
+                                         (uint64_t *)l.tile_bitoff.p, (uint32_t *)l.tile_bits.p, plane_carry,
+                                         (uint32_t *)l.edge_first.p, (uint32_t *)l.edge_last.p, d_error, slot_stride, d_out,
+                                         g, pbounds[q], pbounds[q + 1], epoch);
+                }
+                if (last) {
+                    StageTimer t(ctx, l, ST_ZERO, tl);
+                    launch_finish_sizes(tl, plane_carry, plane_base, (uint64_t *)l.image_bytes.p, g);
+                    launch_join_edges(tl, (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p,
+                                      (const uint32_t *)l.edge_first.p, (const uint32_t *)l.edge_last.p, slot_stride, d_out,
+                                      g);
+                }
+                continue;
+            }
+        }
         {
             StageTimer t(ctx, l, ST_LENGTHS, tl);
             launch_lengths<T>(tl, d_planes, (const uint8_t *)l.k_map.p, (uint16_t *)l.group_bits.p,
@@ -333,6 +361,8 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(l.h_sizes, l.image_bytes.p, (size_t)g.nimages * 8, hipMemcpyDeviceToHost, tl));
+    l.h_sizes[g.nimages] = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&l.h_sizes[g.nimages], d_error, 4, hipMemcpyDeviceToHost, tl));
     HIP_TRY(ctx, hipEventRecord(l.sized, tl));
     return FELICS_OK;
 }
@@ -590,6 +620,11 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
             for (int li = 0; li < used; li++) {
                 Lane &l = ctx->lanes[li];
                 if ((rc = wait_event(ctx, l.sized, "stream sizes")) != 0) return rc;
+                if (!wide && l.h_sizes[l.g.nimages] != 0) {
+                    (void)sync_all(ctx);
+                    ctx->err = "pack: a tile gave up waiting for the offsets of the tiles before it";
+                    return FELICS_E_HIP;
+                }
                 for (size_t i = 0; i < l.g.nimages; i++) {
                     lens[l.first_image + i] = l.h_sizes[i];
                     offsets[l.first_image + i] = (uint64_t)(l.first_image + i) * slot;
@@ -705,7 +740,7 @@ void felics_ctx_destroy(felics_ctx *ctx) {
         if (l.tail) (void)hipStreamSynchronize(l.tail);
         DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map,
                           &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.plane_sums, &l.image_bytes, &l.image_off,
-                          &l.partial, &l.block_tag, &l.wkeys[0], &l.wkeys[1], &l.wvals[0], &l.wvals[1], &l.e_of, &l.heads,
+                          &l.partial, &l.block_tag, &l.status, &l.edge_first, &l.edge_last, &l.wkeys[0], &l.wkeys[1], &l.wvals[0], &l.wvals[1], &l.e_of, &l.heads,
                           &l.sort_temp};
         for (DevBuf *b : bufs) release(*b);
         if (l.h_sizes) (void)hipHostFree(l.h_sizes);

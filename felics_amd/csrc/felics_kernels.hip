@@ -972,7 +972,8 @@ struct LaneBits {
     }
 };
 
-__device__ __forceinline__ void put_pixel(LaneBits &bw, const PixelClass &pc, uint32_t k) {
+template <typename BW>
+__device__ __forceinline__ void put_pixel(BW &bw, const PixelClass &pc, uint32_t k) {
     if (pc.cls == CLS_IN) {  // `1` + phased-in (compression.rs:131-134)
         uint32_t b, nb;
         phase_in(pc.ctx + 1, pc.val, b, nb);
@@ -1066,6 +1067,269 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ pla
         }
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// pack, single pass (gray frames with fixed output slots): lengths, bit offsets and packing of a tile
+// in one kernel.
+//
+// Phase 1: every thread strings the codes of its 16 pixels together into a private LDS buffer
+// (LOCAL_WORDS words; a group with more bits only counts them and is emitted the slow way later).
+// The thread totals are scanned inside the workgroup; the tile's offset in its plane comes from a
+// decoupled look-back over the tiles before it: a tile first publishes its total (AGGREGATE), then
+// wave 0 reads the status words of up to 64 predecessors at a time, adds aggregates until it meets
+// a tile that already knows its inclusive PREFIX, and publishes its own.  A status word is one
+// 64-bit value {epoch, state, bits}, written and read with agent-scope atomics, so it needs no
+// ordering with any other memory; stale words of earlier submissions carry another epoch.
+// Workgroups are dispatched in x-then-y order and a tile only waits for tiles of smaller x in its own
+// row of the grid (or of earlier launches), so everything it waits for has been dispatched; the wait
+// is bounded all the same and reports through `error`.
+// Phase 2: every thread shifts its buffer to its bit offset and ORs it into the LDS window, which
+// is streamed out as in k_pack.  The two words a tile may share with its neighbours go to
+// edge_first / edge_last instead of the output; k_join_edges merges them when all tiles are done,
+// so the output needs no zeroing.
+// ------------------------------------------------------------------------------------------
+
+constexpr uint32_t LOCAL_WORDS = 8;
+constexpr uint32_t ST_AGGREGATE = 1, ST_PREFIX = 2;
+constexpr uint32_t ST_VALUE_BITS = 44;        // bits of a plane fit: < 2^32 pixels x < 2^10 bits
+constexpr uint32_t ST_EPOCH_MASK = 0x3FFFFu;  // 18 bits of the lane's epoch (status is cleared when they wrap)
+constexpr uint32_t LOOKBACK_SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ uint64_t status_word(uint32_t epoch, uint32_t state, uint64_t value) {
+    return ((uint64_t)(((epoch & ST_EPOCH_MASK) << 2) | state) << ST_VALUE_BITS) | value;
+}
+
+// thread-private bit string, MSB-first, word w of thread t at buf[w * PACK_THREADS + t]
+struct LocalBits {
+    uint32_t *buf;
+    uint64_t acc;
+    uint32_t fill, word, total;
+
+    __device__ __forceinline__ void begin(uint32_t *b) {
+        buf = b;
+        acc = 0;
+        fill = word = total = 0;
+    }
+    __device__ __forceinline__ void put(uint32_t v, uint32_t n) {
+        acc |= (uint64_t)v << (64u - fill - n);
+        fill += n;
+        total += n;
+        if (fill >= 32) {
+            if (word < LOCAL_WORDS) buf[word * PACK_THREADS] = (uint32_t)(acc >> 32);
+            acc <<= 32;
+            fill -= 32;
+            word++;
+        }
+    }
+    __device__ __forceinline__ void put_ones(uint32_t q) {
+        while (q >= 32 && word < LOCAL_WORDS) {
+            put(0xFFFFFFFFu, 32);
+            q -= 32;
+        }
+        if (q >= 32) {  // past the buffer: only the count matters
+            total += q & ~31u;
+            word += q >> 5;
+            q &= 31u;
+        }
+        if (q) put((1u << q) - 1u, q);
+    }
+    __device__ __forceinline__ void finish() {
+        if (fill && word < LOCAL_WORDS) buf[word * PACK_THREADS] = (uint32_t)(acc >> 32);
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(PACK_THREADS) void k_pack_fused(const T *__restrict__ planes, const uint8_t *__restrict__ k_map,
+                                                             uint64_t *__restrict__ status, uint64_t *__restrict__ tile_bitoff,
+                                                             uint32_t *__restrict__ tile_bits, uint64_t *__restrict__ plane_carry,
+                                                             uint32_t *__restrict__ edge_first, uint32_t *__restrict__ edge_last,
+                                                             uint32_t *__restrict__ error, uint64_t slot_stride,
+                                                             uint8_t *__restrict__ out, uint32_t W, uint32_t H, uint32_t npix,
+                                                             uint32_t ntiles, uint32_t color, uint32_t depth,
+                                                             uint32_t tile_begin, uint32_t epoch) {
+    __shared__ TileLDS<T> tl;
+    __shared__ uint32_t win[PACK_WIN_WORDS];
+    __shared__ uint32_t lbuf[LOCAL_WORDS * PACK_THREADS];
+    __shared__ uint32_t wsum[PACK_THREADS / 64];
+    __shared__ uint64_t tile_lo_sh;
+    const uint32_t tile = tile_begin + blockIdx.x, plane = blockIdx.y;  // one plane per image
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const T *pl = planes + (uint64_t)plane * npix;
+    const uint32_t tile_first = tile * PACK_TILE;
+    const uint32_t first = tile_first + threadIdx.x * PACK_PER_THREAD;
+    const uint32_t end = min(tile_first + PACK_TILE, npix);
+    const bool has_header = tile == 0 && threadIdx.x == 0;
+    uint64_t *my_status = status + (uint64_t)plane * ntiles + tile;
+
+    stage_tile(tl, pl, k_map + (uint64_t)plane * npix, tile_first, W, npix);
+    __syncthreads();
+
+    // ---- phase 1: this thread's bit string
+    LocalBits lb;
+    lb.begin(lbuf + threadIdx.x);
+    if (first < end) {
+        if (has_header) {  // write_header, format.rs:51-61
+            lb.put(0x464C4353u, 32);  // "FLCS"
+            lb.put((color << 8) | depth, 16);
+            lb.put(W, 32);
+            lb.put(H, 32);
+        }
+        walk_group(tl, pl, first, end, W,
+                   [&](uint32_t, uint32_t rv) {
+                       lb.put(rv, 32);  // write_signed(32, p): sign-extended sample
+                       if (npix == 1) lb.put(0u, 32);
+                   },
+                   [&](const PixelClass &pc, uint32_t k) { put_pixel(lb, pc, k); });
+        lb.finish();
+    }
+    const uint32_t bits = lb.total;
+    const uint32_t inc = wave_incl_scan(bits);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tile_total = 0;
+    for (uint32_t w = 0; w < PACK_THREADS / 64; w++) {
+        if (w < wave) woff += wsum[w];
+        tile_total += wsum[w];
+    }
+
+    // ---- offset of the tile in its plane: decoupled look-back (wave 0)
+    if (wave == 0) {
+        if (lane == 0)
+            __hip_atomic_store(my_status, status_word(epoch, ST_AGGREGATE, tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t excl = 0;
+        int64_t look = (int64_t)tile - 1;  // tile examined by lane 0
+        uint32_t spins = 0;
+        bool failed = false;
+        while (look >= 0) {
+            const int64_t idx = look - (int64_t)lane;
+            uint32_t state = ST_PREFIX;  // in front of tile 0: prefix 0
+            uint64_t value = 0;
+            if (idx >= 0) {
+                const uint64_t sw = __hip_atomic_load(status + (uint64_t)plane * ntiles + (uint64_t)idx, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t tag = (uint32_t)(sw >> ST_VALUE_BITS);
+                state = (tag >> 2) == (epoch & ST_EPOCH_MASK) ? (tag & 3u) : 0u;
+                value = sw & ((1ull << ST_VALUE_BITS) - 1ull);
+            }
+            const uint64_t pm = __ballot(state == ST_PREFIX), vm = __ballot(state != 0);
+            const uint32_t fp = pm ? (uint32_t)__builtin_ctzll(pm) : 64u;  // nearest tile that knows its prefix
+            const uint64_t need = fp >= 63u ? ~0ull : ((2ull << fp) - 1ull);  // lanes 0..fp must have published
+            if ((vm & need) != need) {
+                if (++spins > LOOKBACK_SPIN_LIMIT) {
+                    failed = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            // aggregates of the lanes in front of fp (tile totals, < 2^22 each) and the prefix at fp
+            const uint32_t agg = wave_incl_scan(lane < fp ? (uint32_t)value : 0u);
+            excl += readlane(agg, 63);
+            if (fp < 64u) {
+                excl += ((uint64_t)readlane((uint32_t)(value >> 32), fp) << 32) | readlane((uint32_t)value, fp);
+                break;
+            }
+            look -= 64;
+        }
+        if (failed) {
+            if (lane == 0) atomicOr(error, 1u);
+            excl = ~0ull >> 8;  // far beyond any slot: every store of this tile is dropped
+        }
+        if (lane == 0) {
+            const uint64_t incl = failed ? 0ull : excl + tile_total;
+            __hip_atomic_store(my_status, status_word(epoch, ST_PREFIX, incl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tile_lo_sh = excl;
+            if (!failed) {
+                tile_bitoff[(uint64_t)plane * ntiles + tile] = excl;
+                tile_bits[(uint64_t)plane * ntiles + tile] = tile_total;
+                if (tile + 1 == ntiles) plane_carry[plane] = incl;
+            }
+        }
+    }
+    __syncthreads();
+    const uint64_t tile_lo = tile_lo_sh, tile_hi = tile_lo + tile_total;
+    const uint64_t my_lo = tile_lo + woff + inc - bits;
+    const uint64_t limit_words = slot_stride >> 2;  // a stream that outgrows its slot is cut (the host re-packs)
+    uint32_t *out_words = reinterpret_cast<uint32_t *>(out + (uint64_t)plane * slot_stride);
+    if (tile_total == 0) return;
+    const uint64_t first_word = tile_lo >> 5, last_word = (tile_hi - 1) >> 5;
+    const bool first_shared = (tile_lo & 31u) != 0, last_shared = (tile_hi & 31u) != 0;
+    const bool overflowed = bits > LOCAL_WORDS * 32u;
+
+    // ---- phase 2: window by window
+    for (uint64_t w0 = first_word; w0 <= last_word; w0 += PACK_WIN_WORDS) {
+        for (uint32_t j = threadIdx.x; j < PACK_WIN_WORDS; j += PACK_THREADS) win[j] = 0;
+        __syncthreads();
+        if (bits != 0 && ((my_lo + bits - 1) >> 5) >= w0 && (my_lo >> 5) < w0 + PACK_WIN_WORDS) {
+            if (!overflowed) {
+                const uint32_t shift = (uint32_t)(my_lo & 31u), nsrc = (bits + 31u) >> 5;
+                const uint64_t dw0 = my_lo >> 5;
+                uint32_t prev = 0;
+                for (uint32_t sidx = 0; sidx <= nsrc; sidx++) {
+                    const uint32_t cur = sidx < nsrc ? lbuf[sidx * PACK_THREADS + threadIdx.x] : 0u;
+                    const uint32_t v = shift ? (prev << (32u - shift)) | (cur >> shift) : cur;
+                    prev = cur;
+                    const uint64_t rel = dw0 + sidx - w0;
+                    if (v != 0 && rel < PACK_WIN_WORDS) atomicOr(&win[rel], v);
+                }
+            } else {  // more bits than the private buffer holds: build the codes again, straight into the window
+                LaneBits bw;
+                bw.win = win;
+                bw.win_word0 = w0;
+                bw.begin(my_lo);
+                if (has_header) {
+                    bw.put(0x464C4353u, 32);
+                    bw.put((color << 8) | depth, 16);
+                    bw.put(W, 32);
+                    bw.put(H, 32);
+                }
+                walk_group(tl, pl, first, end, W,
+                           [&](uint32_t, uint32_t rv) {
+                               bw.put(rv, 32);
+                               if (npix == 1) bw.put(0u, 32);
+                           },
+                           [&](const PixelClass &pc, uint32_t k) { put_pixel(bw, pc, k); });
+                bw.finish();
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < PACK_WIN_WORDS; j += PACK_THREADS) {
+            const uint64_t aw = w0 + j;
+            if (aw > last_word) break;
+            const uint32_t v = win[j];
+            if (aw == first_word && first_shared) {
+                edge_first[(uint64_t)plane * ntiles + tile] = v;  // merged with the previous tile's last word later
+            } else if (aw == last_word && last_shared) {
+                edge_last[(uint64_t)plane * ntiles + tile] = v;
+            } else if (aw < limit_words) {
+                out_words[aw] = __builtin_bswap32(v);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Words shared by two tiles (and the last, partly filled word of a plane): OR of the two halves.
+__global__ void k_join_edges(const uint64_t *__restrict__ tile_bitoff, const uint32_t *__restrict__ tile_bits,
+                             const uint32_t *__restrict__ edge_first, const uint32_t *__restrict__ edge_last,
+                             uint64_t slot_stride, uint8_t *__restrict__ out, uint32_t ntiles) {
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x, plane = blockIdx.y;
+    if (tile >= ntiles) return;
+    const uint64_t at = (uint64_t)plane * ntiles + tile;
+    const uint64_t lo = tile_bitoff[at], hi = lo + tile_bits[at];
+    if (hi == lo) return;
+    const uint64_t limit_words = slot_stride >> 2;
+    uint32_t *out_words = reinterpret_cast<uint32_t *>(out + (uint64_t)plane * slot_stride);
+    const uint64_t first_word = lo >> 5, last_word = (hi - 1) >> 5;
+    const bool first_shared = (lo & 31u) != 0, last_shared = (hi & 31u) != 0;
+    if (first_shared && first_word < limit_words) {
+        // the tile before ends inside this word; its half is its edge_last unless it lies inside the word
+        // altogether (then it is the plane's tiny last tile and has no successor, i.e. cannot be `tile - 1`)
+        out_words[first_word] = __builtin_bswap32(edge_first[at] | edge_last[at - 1]);
+    }
+    if (last_shared && tile + 1 == ntiles && !(first_shared && first_word == last_word) && last_word < limit_words)
+        out_words[last_word] = __builtin_bswap32(edge_last[at]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1226,5 +1490,25 @@ template void launch_pack<uint16_t>(hipStream_t, const uint16_t *, const uint8_t
 template void launch_pack<int32_t>(hipStream_t, const int32_t *, const uint8_t *, const uint32_t *, const uint64_t *,
                                    const uint32_t *, const uint64_t *, const uint64_t *, uint64_t, uint8_t *,
                                    const Geometry &, uint32_t, uint32_t);
+
+template <typename T>
+void launch_pack_fused(hipStream_t s, const T *planes, const uint8_t *k_map, uint64_t *status, uint64_t *tile_bitoff,
+                       uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last,
+                       uint32_t *error, uint64_t slot_stride, uint8_t *out, const Geometry &g, uint32_t t0, uint32_t t1,
+                       uint32_t epoch) {
+    if (t1 <= t0) return;
+    hipLaunchKernelGGL((k_pack_fused<T>), dim3(t1 - t0, g.nplanes), dim3(PACK_THREADS), 0, s, planes, k_map, status,
+                       tile_bitoff, tile_bits, plane_carry, edge_first, edge_last, error, slot_stride, out, g.W, g.H, g.npix,
+                       g.pack_tiles, g.color, g.depth, t0, epoch);
+}
+template void launch_pack_fused<uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, uint64_t *, uint64_t *, uint32_t *,
+                                         uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint64_t, uint8_t *,
+                                         const Geometry &, uint32_t, uint32_t, uint32_t);
+
+void launch_join_edges(hipStream_t s, const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint32_t *edge_first,
+                       const uint32_t *edge_last, uint64_t slot_stride, uint8_t *out, const Geometry &g) {
+    hipLaunchKernelGGL(k_join_edges, dim3(cdiv(g.pack_tiles, 256), g.nplanes), dim3(256), 0, s, tile_bitoff, tile_bits,
+                       edge_first, edge_last, slot_stride, out, g.pack_tiles);
+}
 
 }  // namespace felics

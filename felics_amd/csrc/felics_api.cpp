@@ -67,6 +67,9 @@ struct Lane {
 struct felics_ctx {
     int device = -1;
     int max_lanes = 1;          // sub-batches in flight; FELICS_LANES=1..MAX_LANES overrides (tuning)
+    bool two_pass = false;      // FELICS_TWO_PASS=1, or a look-back of the single-pass pack gave up once: lengths + pack kernels
+    bool single_lane = true;    // the submission in flight uses one lane (set per round)
+    bool test_lookback = false; // FELICS_TEST_LOOKBACK_FAIL=1: pretend the first single-pass submission gave up (tests)
     bool poison = false;        // FELICS_POISON=1: overwrite the workspace before every sub-batch (tests)
     bool trace = false;         // FELICS_TRACE=1: synchronise and report after every stage (debugging)
     int timeout_s = 120;        // FELICS_TIMEOUT_S: give up waiting for a submission after this long
@@ -252,7 +255,9 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     if ((epoch & 0x3FFFFu) == 0) HIP_TRY(ctx, hipMemset(l.status.p, 0, l.status.cap));  // look-back tags: 18 epoch bits
     // gray frames with fixed slots: code lengths, tile offsets and packing in one kernel per slice
     const bool pack_by_slice = slot_stride != 0 && g.planes_per_image == 1;
-    const bool fused = pack_by_slice && std::is_same<T, uint8_t>::value && !getenv("FELICS_TWO_PASS");
+    // (one such kernel at a time: the tiles of two of them waiting for each other's queued predecessors
+    // could hold all workgroup slots, so sub-batches running side by side use the two-pass kernels)
+    const bool fused = pack_by_slice && std::is_same<T, uint8_t>::value && !ctx->two_pass && ctx->single_lane;
     uint32_t *d_error = (uint32_t *)l.scalars.p + 8;  // look-back watchdog of the single-pass pack
 
     // ---- front stream
@@ -563,17 +568,19 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
         if (slot < 64 || slot < frame_bytes / 4) slot = 0;
     }
 
-    for (int attempt = 0; attempt < 2; attempt++) {
+    for (int attempt = 0; attempt < 3; attempt++) {
         size_t done = 0;
+        bool lookback_failed = false;
         uint64_t out_base = 0;  // exact placement: where the next round's streams start
         bool overflow = false;
         // Rounds of up to max_lanes sub-batches (one round unless the batch is huge).
-        while (done < n && !overflow) {
+        while (done < n && !overflow && !lookback_failed) {
             const size_t left = n - done;
             const size_t nl = wide ? 1 : std::min<size_t>((size_t)ctx->max_lanes, std::max<size_t>(1, left / MIN_LANE_IMAGES));
             // Later lanes get fewer images (weights nl, nl-1, .., 1): every lane pays the same spine
             // latency, so the lane that starts last should have the least work left after its spine.
             const size_t wsum = nl * (nl + 1) / 2;
+            ctx->single_lane = nl == 1;
             size_t first = done;
             int used = 0;
             for (size_t li = 0; li < nl && first < n; li++) {
@@ -620,11 +627,7 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
             for (int li = 0; li < used; li++) {
                 Lane &l = ctx->lanes[li];
                 if ((rc = wait_event(ctx, l.sized, "stream sizes")) != 0) return rc;
-                if (!wide && l.h_sizes[l.g.nimages] != 0) {
-                    (void)sync_all(ctx);
-                    ctx->err = "pack: a tile gave up waiting for the offsets of the tiles before it";
-                    return FELICS_E_HIP;
-                }
+                if (!wide && (l.h_sizes[l.g.nimages] != 0 || (ctx->test_lookback && !ctx->two_pass))) lookback_failed = true;
                 for (size_t i = 0; i < l.g.nimages; i++) {
                     lens[l.first_image + i] = l.h_sizes[i];
                     offsets[l.first_image + i] = (uint64_t)(l.first_image + i) * slot;
@@ -667,6 +670,13 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
             if ((rc = sync_all(ctx)) != 0) return rc;
             done = first;
         }
+        if (lookback_failed) {
+            // A tile of the single-pass pack gave up waiting for the tiles before it (another context's
+            // kernels holding the GPU, most likely): this context packs in two passes from now on.
+            if ((rc = sync_all(ctx)) != 0) return rc;
+            ctx->two_pass = true;
+            continue;
+        }
         if (!overflow) break;
         slot = 0;  // a stream outgrew its slot: do the batch again with exact placement
     }
@@ -696,6 +706,8 @@ int felics_ctx_create(int device, felics_ctx **out) {
     // caller's stream takes one.  Only effective if the HIP runtime has not been initialised yet.
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
     ctx->poison = getenv("FELICS_POISON") != nullptr;
+    ctx->two_pass = getenv("FELICS_TWO_PASS") != nullptr;
+    ctx->test_lookback = getenv("FELICS_TEST_LOOKBACK_FAIL") != nullptr;
     ctx->trace = getenv("FELICS_TRACE") != nullptr;
     if (const char *e = getenv("FELICS_TIMEOUT_S")) ctx->timeout_s = std::max(1, atoi(e));
     if (const char *e = getenv("FELICS_LANES")) {

@@ -1094,7 +1094,7 @@ constexpr uint32_t LOCAL_WORDS = 8;
 constexpr uint32_t ST_AGGREGATE = 1, ST_PREFIX = 2;
 constexpr uint32_t ST_VALUE_BITS = 44;        // bits of a plane fit: < 2^32 pixels x < 2^10 bits
 constexpr uint32_t ST_EPOCH_MASK = 0x3FFFFu;  // 18 bits of the lane's epoch (status is cleared when they wrap)
-constexpr uint32_t LOOKBACK_SPIN_LIMIT = 1u << 22;
+constexpr uint32_t LOOKBACK_SPIN_LIMIT = 1u << 19;  // polls of >= 1 us each: gives up after about a second
 
 __device__ __forceinline__ uint64_t status_word(uint32_t epoch, uint32_t state, uint64_t value) {
     return ((uint64_t)(((epoch & ST_EPOCH_MASK) << 2) | state) << ST_VALUE_BITS) | value;

@@ -192,6 +192,30 @@ def test_sixteen_bit_4k(enc, oracle):
     _check(enc, oracle, synth.gray16(3840, 2160, 0), "4K gray16")
 
 
+def test_pack_variants(oracle):
+    """The single-pass pack is the default for gray frames; FELICS_TWO_PASS selects the lengths + pack kernels,
+    a look-back that gives up makes the context fall back to them, and sub-batches that run side by side
+    (FELICS_LANES=2) use them as well.  All must produce the oracle's bytes."""
+    import felics_amd
+    from felics_amd import synth
+
+    frames = [synth.gray8(1920, 1080, f, "S1") for f in range(16)] + [synth.gray8(1920, 1080, 3, "S2")]
+    want = [oracle.compress(f) for f in frames]
+    for env in ({}, {"FELICS_TWO_PASS": "1"}, {"FELICS_TEST_LOOKBACK_FAIL": "1"}, {"FELICS_LANES": "2"}):
+        os.environ.update(env)
+        os.environ["FELICS_POISON"] = "1"
+        try:
+            e = felics_amd.Encoder(0)
+        finally:
+            for k in list(env) + ["FELICS_POISON"]:
+                del os.environ[k]
+        try:
+            assert e.compress_batch(frames) == want, env
+            assert e.compress_batch(frames[:3]) == want[:3], env  # the same context again (after a fallback)
+        finally:
+            e.close()
+
+
 def test_errors(enc):
     import felics_amd
 

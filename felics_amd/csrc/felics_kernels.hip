@@ -200,7 +200,10 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
                                                  ET *__restrict__ sorted_e, uint32_t *__restrict__ pix_of,
                                                  uint32_t W, uint32_t npix, uint32_t ntiles, uint32_t tile_begin,
                                                  uint32_t tile_end) {
+    constexpr uint32_t RING = 512;  // a trip adds at most 256 events to fewer than 64 left over
+    static_assert(SORT_TILE <= (1u << 13), "ring records keep the pixel's offset in its tile in 13 bits");
     __shared__ uint32_t runs[4][NCTX];
+    __shared__ uint32_t rings[4][RING];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t tile = tile_begin + blockIdx.x * 4 + wave;
     const uint32_t plane = blockIdx.y;
@@ -217,9 +220,48 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
     const uint32_t begin = tile * SORT_TILE;
     const uint32_t end = min(begin + SORT_TILE, npix);
     // Four rows per trip: their twelve loads are in flight together (one row at a time the kernel waits
-    // for memory once per row); the rows are then ranked and stored one after the other.  (x0, y0) is the
-    // trip's first pixel (scalar); trips inside one image row with x > 0, y > 0 skip the neighbour rule's
-    // case analysis.
+    // for memory once per row).  (x0, y0) is the trip's first pixel (scalar); trips inside one image row
+    // with x > 0, y > 0 skip the neighbour rule's case analysis.
+    uint32_t *ring = rings[wave];
+    uint32_t qhead = 0, qtail = 0;  // ring positions (wave-uniform)
+    // ranks and stores the next n (<= 64) events of the ring
+    auto drain = [&](uint32_t n) {
+        const bool ev = lane < n;
+        const uint32_t rec = ring[(qhead + lane) & (RING - 1u)];
+        const uint32_t c = rec >> 22, e = (rec >> 13) & 0x1FFu, off = rec & 0x1FFFu;
+        // Rank the lanes that share a context with ballots only: every lane learns how many earlier lanes
+        // hold its context (rank) and how many hold it in all (group).  Contexts are matched bit by bit:
+        // after one ballot per context bit every lane holds the mask of the lanes whose context equals its
+        // own -- a fixed cost, however many different contexts the 64 events hold.  Most batches only hold
+        // contexts below 32 and get away with five of the nine bits.
+        const uint64_t ev_mask = __ballot(ev);
+        uint32_t m_lo = (uint32_t)ev_mask, m_hi = (uint32_t)(ev_mask >> 32);
+        auto match_bit = [&](uint32_t b) {
+            const uint32_t t = (uint32_t)((int32_t)(c << (31 - b)) >> 31);  // all ones if bit b of c is set
+            const uint64_t bb = __ballot(ev && t != 0);
+            m_lo &= ~((uint32_t)bb ^ t);
+            m_hi &= ~((uint32_t)(bb >> 32) ^ t);
+        };
+#pragma unroll
+        for (uint32_t b = 0; b < 5; b++) match_bit(b);
+        if (__ballot(ev && c >= 32u) != 0) {  // contexts are < 512
+#pragma unroll
+            for (uint32_t b = 5; b < 9; b++) match_bit(b);
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+        const uint32_t group = (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);
+        const bool leader = ev && rank == 0;  // first lane of its context in this batch
+        // one LDS read per lane (same context -> same address -> broadcast), one write per leader
+        uint32_t dest = 0;
+        if (ev) dest = run[c] + rank;
+        __builtin_amdgcn_wave_barrier();
+        if (leader) run[c] = dest + group;  // the leader has rank 0: dest is the context's running offset
+        __builtin_amdgcn_wave_barrier();
+        if (ev) {
+            sorted_e[dest] = (ET)e;
+            pix_of[dest] = plane_first + begin + off;
+        }
+    };
     uint32_t y0 = begin / W, x0 = begin - y0 * W;
     for (uint32_t row0 = begin; row0 < end; row0 += 256) {
         bool evs[4];
@@ -258,48 +300,23 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
             x0 -= W;
             y0++;
         }
+        // The events of the trip are compacted into a per-wave ring in LDS (raster order kept: row by row,
+        // lane by lane), and ranked / stored 64 at a time: every ballot and every store then works on 64
+        // events instead of the ~35 % of a row's lanes that hold one.
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
-            const uint32_t i = row0 + u * 64 + lane;
-            const bool ev = evs[u];
-            const uint32_t c = cs[u], e = es[u];
-            // Rank the lanes that share a context with ballots only (no memory in the loop): every event
-            // lane learns how many earlier lanes of this row hold its context (rank) and how many lanes
-            // hold it in all (group).  Contexts are matched bit by bit: after one ballot per context bit
-            // every lane holds the mask of the lanes whose context equals its own -- a fixed cost, however
-            // many different contexts the row holds (busy images have 10-40 per row).  Most rows only hold
-            // contexts below 32 and get away with five of the nine bits.
-            uint32_t rank = 0, group = 0;
-            const uint64_t ev_mask = __ballot(ev);
-            if (ev_mask == 0) continue;
-            uint32_t m_lo = (uint32_t)ev_mask, m_hi = (uint32_t)(ev_mask >> 32);
-            auto match_bit = [&](uint32_t b) {
-                const uint32_t t = (uint32_t)((int32_t)(c << (31 - b)) >> 31);  // all ones if bit b of c is set
-                const uint64_t bb = __ballot(ev && t != 0);
-                m_lo &= ~((uint32_t)bb ^ t);
-                m_hi &= ~((uint32_t)(bb >> 32) ^ t);
-            };
-#pragma unroll
-            for (uint32_t b = 0; b < 5; b++) match_bit(b);
-            if (__ballot(ev && c >= 32u) != 0) {  // contexts are < 512
-#pragma unroll
-                for (uint32_t b = 5; b < 9; b++) match_bit(b);
-            }
-            rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
-            group = (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);
-            const bool leader = ev && rank == 0;  // first lane of its context in this row
-            // one LDS read per lane (same context -> same address -> broadcast), one write per leader
-            uint32_t dest = 0;
-            if (ev) dest = run[c] + rank;
-            __builtin_amdgcn_wave_barrier();
-            if (leader) run[c] = dest + group;  // the leader has rank 0: dest is the context's running offset
-            __builtin_amdgcn_wave_barrier();
-            if (ev) {
-                sorted_e[dest] = (ET)e;
-                pix_of[dest] = plane_first + i;
-            }
+            const uint64_t m = __ballot(evs[u]);
+            if (m == 0) continue;
+            if (evs[u]) ring[(qtail + mbcnt(m)) & (RING - 1u)] = (cs[u] << 22) | (es[u] << 13) | (row0 - begin + u * 64 + lane);
+            qtail += (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        while (qtail - qhead >= 64u) {
+            drain(64u);
+            qhead += 64u;
         }
     }
+    if (qtail != qhead) drain(qtail - qhead);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -462,13 +462,12 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
                 // (the block-level test said a halving exists, and after a halving the loop is only
                 // re-entered when the end state says there is another: hm is never empty here)
                 const uint32_t f = (uint32_t)__ffsll((long long)hm) - 1u;
-                const uint32_t f0 = readlane(P0, f), f1 = readlane(P1, f), f2 = readlane(P2, f);
-                const uint32_t f3 = readlane(P3, f), f4 = readlane(P4, f), f5 = readlane(P5, f);
-                // S <- ((S + P(f)) >> 1) - P(f): later lanes add their own P(t) >= P(f) back (mod 2^32)
-                S0 = ((S0 + f0) >> 1) - f0; S1 = ((S1 + f1) >> 1) - f1; S2 = ((S2 + f2) >> 1) - f2;
-                S3 = ((S3 + f3) >> 1) - f3; S4 = ((S4 + f4) >> 1) - f4; S5 = ((S5 + f5) >> 1) - f5;
-                const uint32_t s01 = l7 == 0 ? S0 : S1, s23 = l7 == 2 ? S2 : S3, s45 = l7 == 4 ? S4 : S5;
-                Sv = l7 < 2 ? s01 : l7 < 4 ? s23 : l7 < 6 ? s45 : 0u;
+                // S <- ((S + P(f)) >> 1) - P(f): later lanes add their own P(t) >= P(f) back (mod 2^32).
+                // Done on the state vector itself: lane l picks P_{l & 7}(f) out of the three packed scans.
+                const uint32_t q01 = readlane(p01, f), q23 = readlane(p23, f), q45 = readlane(p45, f);
+                const uint32_t qv = l7 < 2 ? q01 : l7 < 4 ? q23 : l7 < 6 ? q45 : 0u;
+                const uint32_t Pf = (qv >> ((l7 & 1u) << 4)) & 0xFFFFu;
+                Sv = ((Sv + Pf) >> 1) - Pf;
                 lo = f + 1;
                 // state at the end of the block if nothing else happens (block sums = prefix sums at
                 // lane 63); another round only if that still has all six counters above 1024

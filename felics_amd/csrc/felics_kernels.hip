@@ -939,6 +939,7 @@ __global__ void k_zero_streams(uint32_t *__restrict__ out, const uint64_t *__res
 
 struct LaneBits {
     uint32_t *win;       // LDS window
+    uint32_t win_words;  // its size
     uint64_t win_word0;  // absolute word index of win[0]
     uint64_t cur_word;   // absolute word being filled
     uint64_t acc;        // bits of cur_word in the top half, overflow below
@@ -952,7 +953,7 @@ struct LaneBits {
     __device__ __forceinline__ void emit(uint32_t w) {
         if (w) {
             const uint64_t rel = cur_word - win_word0;
-            if (rel < PACK_WIN_WORDS) atomicOr(&win[rel], w);  // also false when cur_word < win_word0
+            if (rel < win_words) atomicOr(&win[rel], w);  // also false when cur_word < win_word0
         }
     }
     // append the low n bits of v (v < 2^n, 1 <= n <= 32), most significant first
@@ -975,7 +976,7 @@ struct LaneBits {
             const uint64_t n = q >> 5;
             if (n) {
                 const uint64_t lo = cur_word > win_word0 ? cur_word : win_word0;
-                const uint64_t hi = cur_word + n < win_word0 + PACK_WIN_WORDS ? cur_word + n : win_word0 + PACK_WIN_WORDS;
+                const uint64_t hi = cur_word + n < win_word0 + win_words ? cur_word + n : win_word0 + win_words;
                 for (uint64_t w = lo; w < hi; w++) atomicOr(&win[w - win_word0], 0xFFFFFFFFu);
                 cur_word += n;
                 q &= 31u;
@@ -1054,6 +1055,7 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ pla
         if (bits != 0 && ((my_lo + bits - 1) >> 5) >= w0 && (my_lo >> 5) < w0 + PACK_WIN_WORDS) {
             LaneBits bw;
             bw.win = win;
+            bw.win_words = PACK_WIN_WORDS;
             bw.win_word0 = w0;
             bw.begin(my_lo);
             if (has_header) {  // write_header, format.rs:51-61
@@ -1107,6 +1109,7 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ pla
 // ------------------------------------------------------------------------------------------
 
 constexpr uint32_t LOCAL_WORDS = 8;
+constexpr uint32_t FUSED_WIN_WORDS = 1280;  // LDS bit window: 10 bits per pixel of a tile in one pass (more bits: more passes)
 constexpr uint32_t ST_AGGREGATE = 1, ST_PREFIX = 2;
 constexpr uint32_t ST_VALUE_BITS = 44;        // bits of a plane fit: < 2^32 pixels x < 2^10 bits
 constexpr uint32_t ST_EPOCH_MASK = 0x3FFFFu;  // 18 bits of the lane's epoch (status is cleared when they wrap)
@@ -1155,8 +1158,9 @@ struct LocalBits {
     }
 };
 
+// (six waves per SIMD: 80 VGPRs, 25.6 KB of LDS per workgroup)
 template <typename T>
-__global__ __launch_bounds__(PACK_THREADS) void k_pack_fused(const T *__restrict__ planes, const uint8_t *__restrict__ k_map,
+__attribute__((amdgpu_waves_per_eu(6))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_fused(const T *__restrict__ planes, const uint8_t *__restrict__ k_map,
                                                              uint64_t *__restrict__ status, uint64_t *__restrict__ tile_bitoff,
                                                              uint32_t *__restrict__ tile_bits, uint64_t *__restrict__ plane_carry,
                                                              uint32_t *__restrict__ edge_first, uint32_t *__restrict__ edge_last,
@@ -1165,7 +1169,7 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack_fused(const T *__restrict
                                                              uint32_t ntiles, uint32_t color, uint32_t depth,
                                                              uint32_t tile_begin, uint32_t epoch) {
     __shared__ TileLDS<T> tl;
-    __shared__ uint32_t win[PACK_WIN_WORDS];
+    __shared__ uint32_t win[FUSED_WIN_WORDS];
     __shared__ uint32_t lbuf[LOCAL_WORDS * PACK_THREADS];
     __shared__ uint32_t wsum[PACK_THREADS / 64];
     __shared__ uint64_t tile_lo_sh;
@@ -1209,7 +1213,8 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack_fused(const T *__restrict
         tile_total += wsum[w];
     }
 
-    // ---- offset of the tile in its plane: decoupled look-back (wave 0)
+    // ---- offset of the tile in its plane: decoupled look-back (wave 0); the others clear the bit window
+    for (uint32_t j = threadIdx.x; j < FUSED_WIN_WORDS; j += PACK_THREADS) win[j] = 0;
     if (wave == 0) {
         if (lane == 0)
             __hip_atomic_store(my_status, status_word(epoch, ST_AGGREGATE, tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1274,10 +1279,13 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack_fused(const T *__restrict
     const bool overflowed = bits > LOCAL_WORDS * 32u;
 
     // ---- phase 2: window by window
-    for (uint64_t w0 = first_word; w0 <= last_word; w0 += PACK_WIN_WORDS) {
-        for (uint32_t j = threadIdx.x; j < PACK_WIN_WORDS; j += PACK_THREADS) win[j] = 0;
-        __syncthreads();
-        if (bits != 0 && ((my_lo + bits - 1) >> 5) >= w0 && (my_lo >> 5) < w0 + PACK_WIN_WORDS) {
+    for (uint64_t w0 = first_word; w0 <= last_word; w0 += FUSED_WIN_WORDS) {
+        if (w0 != first_word) {  // (the first window was cleared above)
+            __syncthreads();
+            for (uint32_t j = threadIdx.x; j < FUSED_WIN_WORDS; j += PACK_THREADS) win[j] = 0;
+            __syncthreads();
+        }
+        if (bits != 0 && ((my_lo + bits - 1) >> 5) >= w0 && (my_lo >> 5) < w0 + FUSED_WIN_WORDS) {
             if (!overflowed) {
                 const uint32_t shift = (uint32_t)(my_lo & 31u), nsrc = (bits + 31u) >> 5;
                 const uint64_t dw0 = my_lo >> 5;
@@ -1287,11 +1295,12 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack_fused(const T *__restrict
                     const uint32_t v = shift ? (prev << (32u - shift)) | (cur >> shift) : cur;
                     prev = cur;
                     const uint64_t rel = dw0 + sidx - w0;
-                    if (v != 0 && rel < PACK_WIN_WORDS) atomicOr(&win[rel], v);
+                    if (v != 0 && rel < FUSED_WIN_WORDS) atomicOr(&win[rel], v);
                 }
             } else {  // more bits than the private buffer holds: build the codes again, straight into the window
                 LaneBits bw;
                 bw.win = win;
+                bw.win_words = FUSED_WIN_WORDS;
                 bw.win_word0 = w0;
                 bw.begin(my_lo);
                 if (has_header) {
@@ -1310,7 +1319,7 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack_fused(const T *__restrict
             }
         }
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < PACK_WIN_WORDS; j += PACK_THREADS) {
+        for (uint32_t j = threadIdx.x; j < FUSED_WIN_WORDS; j += PACK_THREADS) {
             const uint64_t aw = w0 + j;
             if (aw > last_word) break;
             const uint32_t v = win[j];
@@ -1322,7 +1331,6 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack_fused(const T *__restrict
                 out_words[aw] = __builtin_bswap32(v);
             }
         }
-        __syncthreads();
     }
 }
 

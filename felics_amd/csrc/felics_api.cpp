@@ -53,7 +53,7 @@ struct Lane {
     uint64_t *h_sizes = nullptr;      // pinned: image_bytes[n] followed by image_off[n + 1]
     size_t h_sizes_cap = 0;
     DevBuf planes, counts, chain_len, chain_base, chain_prog, scalars, sorted_e, pix_of, k_map, block_state, group_bits,
-        tile_bits, tile_bitoff, plane_sums, image_bytes, image_off, partial, block_tag, status, edge_first, edge_last;
+        tile_bits, tile_bitoff, plane_sums, image_bytes, image_off, partial, block_tag, status, edge_first, edge_last, pscratch;
     DevBuf wkeys[2], wvals[2], e_of, heads, sort_temp;  // 16-bit samples: sort records, Rice operands, chain heads
     uint32_t epoch = 0;               // sub-batches this lane has run: block tags are (epoch, slice)
     // the sub-batch in flight
@@ -253,18 +253,28 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     }
     const uint32_t epoch = l.epoch;
     if ((epoch & 0x3FFFFu) == 0) HIP_TRY(ctx, hipMemset(l.status.p, 0, l.status.cap));  // look-back tags: 18 epoch bits
-    // gray frames with fixed slots: code lengths, tile offsets and packing in one kernel per slice
+    // Fixed slots: code lengths, tile offsets and packing in one kernel per slice (one such kernel at a
+    // time: the tiles of two of them waiting for each other's queued predecessors could hold all workgroup
+    // slots, so sub-batches running side by side use the two-pass kernels).  It puts planes 1, 2 of an RGB
+    // image into scratch slots of their own and moves them behind plane 0 at the end.
+    const bool fused = slot_stride != 0 && !ctx->two_pass && ctx->single_lane;
+    // Two-pass kernels: gray frames pack slice by slice; RGB packs after the last slice (the offset of planes
+    // 1 and 2 in their stream needs the size of the planes before them).
     const bool pack_by_slice = slot_stride != 0 && g.planes_per_image == 1;
-    // (one such kernel at a time: the tiles of two of them waiting for each other's queued predecessors
-    // could hold all workgroup slots, so sub-batches running side by side use the two-pass kernels)
-    const bool fused = pack_by_slice && std::is_same<T, uint8_t>::value && !ctx->two_pass && ctx->single_lane;
+    PackTarget target{d_out, slot_stride, nullptr, 0};
+    if (fused && g.planes_per_image > 1) {
+        target.plane_slot = ((uint64_t)g.npix + g.npix / 4 + 64 + 15) & ~15ull;
+        if ((rc = reserve(ctx, l.pscratch, (size_t)(target.plane_slot * g.nimages * (g.planes_per_image - 1)))) != 0) return rc;
+        target.scratch = (uint8_t *)l.pscratch.p;
+    }
     uint32_t *d_error = (uint32_t *)l.scalars.p + 8;  // look-back watchdog of the single-pass pack
 
     // ---- front stream
     if (ctx->poison) {  // FELICS_POISON: every intermediate buffer starts as garbage, as on a fresh context
         DevBuf *bufs[] = {&l.counts, &l.chain_len, &l.chain_base, &l.sorted_e, &l.pix_of, &l.k_map, &l.block_state,
-                          &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.edge_first, &l.edge_last};
-        for (DevBuf *b : bufs) HIP_TRY(ctx, hipMemsetAsync(b->p, 0xA5, b->cap, f));
+                          &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.edge_first, &l.edge_last, &l.pscratch};
+        for (DevBuf *b : bufs)
+            if (b->p) HIP_TRY(ctx, hipMemsetAsync(b->p, 0xA5, b->cap, f));
     }
     {
         StageTimer t(ctx, l, ST_HIST, f);
@@ -319,24 +329,22 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         HIP_TRY(ctx, hipStreamWaitEvent(tl, l.assign_done[q], 0));
         const bool last = q + 1 == SLICES;
         if (bounds[q + 1] == bounds[q] && !last) continue;
-        if constexpr (std::is_same<T, uint8_t>::value) {
-            if (fused) {
-                {
-                    StageTimer t(ctx, l, ST_PACK, tl);
-                    launch_pack_fused<T>(tl, d_planes, (const uint8_t *)l.k_map.p, (uint64_t *)l.status.p,
-                                         (uint64_t *)l.tile_bitoff.p, (uint32_t *)l.tile_bits.p, plane_carry,
-                                         (uint32_t *)l.edge_first.p, (uint32_t *)l.edge_last.p, d_error, slot_stride, d_out,
-                                         g, pbounds[q], pbounds[q + 1], epoch);
-                }
-                if (last) {
-                    StageTimer t(ctx, l, ST_ZERO, tl);
-                    launch_finish_sizes(tl, plane_carry, plane_base, (uint64_t *)l.image_bytes.p, g);
-                    launch_join_edges(tl, (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p,
-                                      (const uint32_t *)l.edge_first.p, (const uint32_t *)l.edge_last.p, slot_stride, d_out,
-                                      g);
-                }
-                continue;
+        if (fused) {
+            {
+                StageTimer t(ctx, l, ST_PACK, tl);
+                launch_pack_fused<T>(tl, d_planes, (const uint8_t *)l.k_map.p, (uint64_t *)l.status.p,
+                                     (uint64_t *)l.tile_bitoff.p, (uint32_t *)l.tile_bits.p, plane_carry,
+                                     (uint32_t *)l.edge_first.p, (uint32_t *)l.edge_last.p, d_error, target, g, pbounds[q],
+                                     pbounds[q + 1], epoch);
             }
+            if (last) {
+                StageTimer t(ctx, l, ST_ZERO, tl);
+                launch_finish_sizes(tl, plane_carry, plane_base, (uint64_t *)l.image_bytes.p, g);
+                launch_join_edges(tl, (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p,
+                                  (const uint32_t *)l.edge_first.p, (const uint32_t *)l.edge_last.p, target, g);
+                launch_concat_planes(tl, plane_base, plane_carry, target, g);
+            }
+            continue;
         }
         {
             StageTimer t(ctx, l, ST_LENGTHS, tl);
@@ -627,7 +635,8 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
             for (int li = 0; li < used; li++) {
                 Lane &l = ctx->lanes[li];
                 if ((rc = wait_event(ctx, l.sized, "stream sizes")) != 0) return rc;
-                if (!wide && (l.h_sizes[l.g.nimages] != 0 || (ctx->test_lookback && !ctx->two_pass))) lookback_failed = true;
+                if (!wide && ((l.h_sizes[l.g.nimages] & 1u) != 0 || (ctx->test_lookback && !ctx->two_pass))) lookback_failed = true;
+                if (!wide && (l.h_sizes[l.g.nimages] & 2u) != 0) overflow = true;  // an RGB plane outgrew its scratch slot
                 for (size_t i = 0; i < l.g.nimages; i++) {
                     lens[l.first_image + i] = l.h_sizes[i];
                     offsets[l.first_image + i] = (uint64_t)(l.first_image + i) * slot;
@@ -752,7 +761,7 @@ void felics_ctx_destroy(felics_ctx *ctx) {
         if (l.tail) (void)hipStreamSynchronize(l.tail);
         DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map,
                           &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.plane_sums, &l.image_bytes, &l.image_off,
-                          &l.partial, &l.block_tag, &l.status, &l.edge_first, &l.edge_last, &l.wkeys[0], &l.wkeys[1], &l.wvals[0], &l.wvals[1], &l.e_of, &l.heads,
+                          &l.partial, &l.block_tag, &l.status, &l.edge_first, &l.edge_last, &l.pscratch, &l.wkeys[0], &l.wkeys[1], &l.wvals[0], &l.wvals[1], &l.e_of, &l.heads,
                           &l.sort_temp};
         for (DevBuf *b : bufs) release(*b);
         if (l.h_sizes) (void)hipHostFree(l.h_sizes);

@@ -114,19 +114,28 @@ void launch_pack(hipStream_t s, const T *planes, const uint8_t *k_map, const gro
                  const uint64_t *image_off, uint64_t slot_stride, uint8_t *out, const Geometry &g, uint32_t t0,
                  uint32_t t1);
 
-// Single-pass pack for gray frames with fixed output slots (one plane per image, plane p's stream at
-// p * slot_stride): code lengths, tile offsets (decoupled look-back through `status`, one u64 per tile,
-// zero-initialised once, `epoch` distinguishes submissions) and packing in one kernel per slice of tiles.
-// Writes tile_bitoff / tile_bits / plane_carry like the lengths + bitscan kernels.  The words two tiles
-// share are left in edge_first / edge_last; launch_join_edges stores them once every tile is done.
-// *error becomes non-zero if a look-back gave up waiting.
+// Single-pass pack for 8-bit frames with fixed output slots (image i's stream at out + i * slot_stride):
+// code lengths, tile offsets (decoupled look-back through `status`, one u64 per tile, zero-initialised
+// once, `epoch` distinguishes submissions) and packing in one kernel per slice of tiles.  Writes
+// tile_bitoff / tile_bits / plane_carry like the lengths + bitscan kernels.  The words two tiles share are
+// left in edge_first / edge_last; launch_join_edges stores them once every tile is done.  Planes 1, 2 of
+// an RGB image are packed into scratch slots (plane c of image i at scratch + (2 i + c - 1) * plane_slot)
+// and moved behind plane 0 by launch_concat_planes after launch_finish_sizes.
+// *error: bit 0 = a look-back gave up waiting, bit 1 = a plane outgrew its scratch slot.
+struct PackTarget {
+    uint8_t *out;
+    uint64_t slot_stride;
+    uint8_t *scratch;
+    uint64_t plane_slot;
+};
 template <typename T>
 void launch_pack_fused(hipStream_t s, const T *planes, const uint8_t *k_map, uint64_t *status, uint64_t *tile_bitoff,
                        uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last,
-                       uint32_t *error, uint64_t slot_stride, uint8_t *out, const Geometry &g, uint32_t t0, uint32_t t1,
-                       uint32_t epoch);
+                       uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t t0, uint32_t t1, uint32_t epoch);
 void launch_join_edges(hipStream_t s, const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint32_t *edge_first,
-                       const uint32_t *edge_last, uint64_t slot_stride, uint8_t *out, const Geometry &g);
+                       const uint32_t *edge_last, const PackTarget &to, const Geometry &g);
+void launch_concat_planes(hipStream_t s, const uint64_t *plane_base, const uint64_t *plane_carry, const PackTarget &to,
+                          const Geometry &g);
 
 // ---- 16-bit samples (felics_wide.hip): contexts 0..131070 and 15 Rice parameters (traits.rs:35-43).
 // The events of a batch are ordered by (plane, context) with a stable radix sort and every context's

@@ -1108,6 +1108,28 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ pla
 // so the output needs no zeroing.
 // ------------------------------------------------------------------------------------------
 
+// Where the single-pass pack puts a plane's bits.  Plane 0 of an image goes to the image's slot of the
+// output (header first); planes 1, 2 of an RGB image are packed as bit strings of their own into scratch
+// slots and moved behind plane 0 by k_concat_planes once every size is known (compression.rs:365-367:
+// the planes of an image follow each other without alignment).
+struct PlaneOut {
+    uint8_t *out;
+    uint64_t slot_stride;  // image i's stream starts at out + i * slot_stride
+    uint8_t *scratch;
+    uint64_t plane_slot;   // plane c >= 1 of image i at scratch + (i * (planes_per_image - 1) + c - 1) * plane_slot
+    uint32_t planes_per_image;
+};
+
+__device__ __forceinline__ uint32_t *plane_words(const PlaneOut &po, uint32_t plane, uint64_t &limit_words) {
+    const uint32_t img = plane / po.planes_per_image, c = plane - img * po.planes_per_image;
+    if (c == 0) {
+        limit_words = po.slot_stride >> 2;
+        return reinterpret_cast<uint32_t *>(po.out + (uint64_t)img * po.slot_stride);
+    }
+    limit_words = po.plane_slot >> 2;
+    return reinterpret_cast<uint32_t *>(po.scratch + ((uint64_t)img * (po.planes_per_image - 1) + c - 1) * po.plane_slot);
+}
+
 constexpr uint32_t LOCAL_WORDS = 8;
 constexpr uint32_t FUSED_WIN_WORDS = 1280;  // LDS bit window: 10 bits per pixel of a tile in one pass (more bits: more passes)
 constexpr uint32_t ST_AGGREGATE = 1, ST_PREFIX = 2;
@@ -1158,28 +1180,28 @@ struct LocalBits {
     }
 };
 
-// (six waves per SIMD: 80 VGPRs, 25.6 KB of LDS per workgroup)
+// (u8 planes: six waves per SIMD -- 80 VGPRs, 25.6 KB of LDS per workgroup; i16 planes: four, 33.8 KB)
 template <typename T>
-__attribute__((amdgpu_waves_per_eu(6))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_fused(const T *__restrict__ planes, const uint8_t *__restrict__ k_map,
+__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_fused(const T *__restrict__ planes, const uint8_t *__restrict__ k_map,
                                                              uint64_t *__restrict__ status, uint64_t *__restrict__ tile_bitoff,
                                                              uint32_t *__restrict__ tile_bits, uint64_t *__restrict__ plane_carry,
                                                              uint32_t *__restrict__ edge_first, uint32_t *__restrict__ edge_last,
-                                                             uint32_t *__restrict__ error, uint64_t slot_stride,
-                                                             uint8_t *__restrict__ out, uint32_t W, uint32_t H, uint32_t npix,
-                                                             uint32_t ntiles, uint32_t color, uint32_t depth,
+                                                             uint32_t *__restrict__ error, PlaneOut po, uint32_t W, uint32_t H,
+                                                             uint32_t npix, uint32_t ntiles, uint32_t color, uint32_t depth,
                                                              uint32_t tile_begin, uint32_t epoch) {
     __shared__ TileLDS<T> tl;
     __shared__ uint32_t win[FUSED_WIN_WORDS];
     __shared__ uint32_t lbuf[LOCAL_WORDS * PACK_THREADS];
     __shared__ uint32_t wsum[PACK_THREADS / 64];
     __shared__ uint64_t tile_lo_sh;
-    const uint32_t tile = tile_begin + blockIdx.x, plane = blockIdx.y;  // one plane per image
+    const uint32_t tile = tile_begin + blockIdx.x, plane = blockIdx.y;
+    const bool first_plane = plane % po.planes_per_image == 0;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const T *pl = planes + (uint64_t)plane * npix;
     const uint32_t tile_first = tile * PACK_TILE;
     const uint32_t first = tile_first + threadIdx.x * PACK_PER_THREAD;
     const uint32_t end = min(tile_first + PACK_TILE, npix);
-    const bool has_header = tile == 0 && threadIdx.x == 0;
+    const bool has_header = tile == 0 && threadIdx.x == 0 && first_plane;
     uint64_t *my_status = status + (uint64_t)plane * ntiles + tile;
 
     stage_tile(tl, pl, k_map + (uint64_t)plane * npix, tile_first, W, npix);
@@ -1264,15 +1286,18 @@ __attribute__((amdgpu_waves_per_eu(6))) __global__ __launch_bounds__(PACK_THREAD
             if (!failed) {
                 tile_bitoff[(uint64_t)plane * ntiles + tile] = excl;
                 tile_bits[(uint64_t)plane * ntiles + tile] = tile_total;
-                if (tile + 1 == ntiles) plane_carry[plane] = incl;
+                if (tile + 1 == ntiles) {
+                    plane_carry[plane] = incl;
+                    if (!first_plane && incl > po.plane_slot * 8u) atomicOr(error, 2u);  // the plane outgrew its scratch slot
+                }
             }
         }
     }
     __syncthreads();
     const uint64_t tile_lo = tile_lo_sh, tile_hi = tile_lo + tile_total;
     const uint64_t my_lo = tile_lo + woff + inc - bits;
-    const uint64_t limit_words = slot_stride >> 2;  // a stream that outgrows its slot is cut (the host re-packs)
-    uint32_t *out_words = reinterpret_cast<uint32_t *>(out + (uint64_t)plane * slot_stride);
+    uint64_t limit_words;  // a stream that outgrows its slot is cut (the host re-packs)
+    uint32_t *out_words = plane_words(po, plane, limit_words);
     if (tile_total == 0) return;
     const uint64_t first_word = tile_lo >> 5, last_word = (tile_hi - 1) >> 5;
     const bool first_shared = (tile_lo & 31u) != 0, last_shared = (tile_hi & 31u) != 0;
@@ -1336,15 +1361,15 @@ __attribute__((amdgpu_waves_per_eu(6))) __global__ __launch_bounds__(PACK_THREAD
 
 // Words shared by two tiles (and the last, partly filled word of a plane): OR of the two halves.
 __global__ void k_join_edges(const uint64_t *__restrict__ tile_bitoff, const uint32_t *__restrict__ tile_bits,
-                             const uint32_t *__restrict__ edge_first, const uint32_t *__restrict__ edge_last,
-                             uint64_t slot_stride, uint8_t *__restrict__ out, uint32_t ntiles) {
+                             const uint32_t *__restrict__ edge_first, const uint32_t *__restrict__ edge_last, PlaneOut po,
+                             uint32_t ntiles) {
     const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x, plane = blockIdx.y;
     if (tile >= ntiles) return;
     const uint64_t at = (uint64_t)plane * ntiles + tile;
     const uint64_t lo = tile_bitoff[at], hi = lo + tile_bits[at];
     if (hi == lo) return;
-    const uint64_t limit_words = slot_stride >> 2;
-    uint32_t *out_words = reinterpret_cast<uint32_t *>(out + (uint64_t)plane * slot_stride);
+    uint64_t limit_words;
+    uint32_t *out_words = plane_words(po, plane, limit_words);
     const uint64_t first_word = lo >> 5, last_word = (hi - 1) >> 5;
     const bool first_shared = (lo & 31u) != 0, last_shared = (hi & 31u) != 0;
     if (first_shared && first_word < limit_words) {
@@ -1354,6 +1379,42 @@ __global__ void k_join_edges(const uint64_t *__restrict__ tile_bitoff, const uin
     }
     if (last_shared && tile + 1 == ntiles && !(first_shared && first_word == last_word) && last_word < limit_words)
         out_words[last_word] = __builtin_bswap32(edge_last[at]);
+}
+
+// 32 bits of a plane's own bit string (nbits long, zero beyond) starting at bit p (may be negative)
+__device__ __forceinline__ uint32_t plane_bits_at(const uint32_t *__restrict__ src, uint64_t nbits, int64_t p) {
+    const int64_t w0 = p >> 5;  // floor
+    const uint32_t sh = (uint32_t)(p & 31);
+    auto word = [&](int64_t i) -> uint32_t {
+        return (i >= 0 && (uint64_t)i * 32u < nbits) ? __builtin_bswap32(src[i]) : 0u;
+    };
+    const uint32_t a = word(w0);
+    if (sh == 0) return a;
+    return (a << sh) | (word(w0 + 1) >> (32u - sh));
+}
+
+// RGB: moves planes 1.. of every image from their scratch slots to their place behind plane 0.
+// plane_base[p] = bit offset of plane p in its image's stream, plane_carry[p] = its bits (k_finish_sizes).
+// One thread per output word: it ORs what every plane contributes to that word (the first word also
+// keeps plane 0's last bits, already in place).
+__global__ __launch_bounds__(256) void k_concat_planes(const uint64_t *__restrict__ plane_base,
+                                                       const uint64_t *__restrict__ plane_carry, PlaneOut po) {
+    const uint32_t img = blockIdx.y, ppi = po.planes_per_image;
+    const uint64_t *base = plane_base + (uint64_t)img * ppi, *bits = plane_carry + (uint64_t)img * ppi;
+    const uint64_t begin_bit = base[1], end_bit = base[ppi - 1] + bits[ppi - 1];
+    if (end_bit == begin_bit) return;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(po.out + (uint64_t)img * po.slot_stride);
+    const uint64_t first_word = begin_bit >> 5, last_word = (end_bit - 1) >> 5, limit_words = po.slot_stride >> 2;
+    for (uint64_t w = first_word + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w <= last_word && w < limit_words;
+         w += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = (w == first_word && (begin_bit & 31u) != 0) ? __builtin_bswap32(dst[w]) : 0u;
+        for (uint32_t c = 1; c < ppi; c++) {
+            uint64_t lim;
+            const uint32_t *src = plane_words(po, img * ppi + c, lim);
+            v |= plane_bits_at(src, bits[c], (int64_t)(w * 32u) - (int64_t)base[c]);
+        }
+        dst[w] = __builtin_bswap32(v);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1518,21 +1579,35 @@ template void launch_pack<int32_t>(hipStream_t, const int32_t *, const uint8_t *
 template <typename T>
 void launch_pack_fused(hipStream_t s, const T *planes, const uint8_t *k_map, uint64_t *status, uint64_t *tile_bitoff,
                        uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last,
-                       uint32_t *error, uint64_t slot_stride, uint8_t *out, const Geometry &g, uint32_t t0, uint32_t t1,
-                       uint32_t epoch) {
+                       uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t t0, uint32_t t1, uint32_t epoch) {
     if (t1 <= t0) return;
+    const PlaneOut po{to.out, to.slot_stride, to.scratch, to.plane_slot, g.planes_per_image};
     hipLaunchKernelGGL((k_pack_fused<T>), dim3(t1 - t0, g.nplanes), dim3(PACK_THREADS), 0, s, planes, k_map, status,
-                       tile_bitoff, tile_bits, plane_carry, edge_first, edge_last, error, slot_stride, out, g.W, g.H, g.npix,
+                       tile_bitoff, tile_bits, plane_carry, edge_first, edge_last, error, po, g.W, g.H, g.npix,
                        g.pack_tiles, g.color, g.depth, t0, epoch);
 }
 template void launch_pack_fused<uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, uint64_t *, uint64_t *, uint32_t *,
-                                         uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint64_t, uint8_t *,
+                                         uint64_t *, uint32_t *, uint32_t *, uint32_t *, const PackTarget &,
+                                         const Geometry &, uint32_t, uint32_t, uint32_t);
+template void launch_pack_fused<int16_t>(hipStream_t, const int16_t *, const uint8_t *, uint64_t *, uint64_t *, uint32_t *,
+                                         uint64_t *, uint32_t *, uint32_t *, uint32_t *, const PackTarget &,
                                          const Geometry &, uint32_t, uint32_t, uint32_t);
 
 void launch_join_edges(hipStream_t s, const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint32_t *edge_first,
-                       const uint32_t *edge_last, uint64_t slot_stride, uint8_t *out, const Geometry &g) {
+                       const uint32_t *edge_last, const PackTarget &to, const Geometry &g) {
+    const PlaneOut po{to.out, to.slot_stride, to.scratch, to.plane_slot, g.planes_per_image};
     hipLaunchKernelGGL(k_join_edges, dim3(cdiv(g.pack_tiles, 256), g.nplanes), dim3(256), 0, s, tile_bitoff, tile_bits,
-                       edge_first, edge_last, slot_stride, out, g.pack_tiles);
+                       edge_first, edge_last, po, g.pack_tiles);
+}
+
+void launch_concat_planes(hipStream_t s, const uint64_t *plane_base, const uint64_t *plane_carry, const PackTarget &to,
+                          const Geometry &g) {
+    if (g.planes_per_image < 2) return;
+    const PlaneOut po{to.out, to.slot_stride, to.scratch, to.plane_slot, g.planes_per_image};
+    // the planes behind plane 0 hold at most plane_slot bytes each: enough threads for that many words
+    const uint64_t words = (to.plane_slot >> 2) * (g.planes_per_image - 1);
+    const uint32_t bx = (uint32_t)std::min<uint64_t>(cdiv(words, 256 * 4), 2048u);
+    hipLaunchKernelGGL(k_concat_planes, dim3(std::max(bx, 1u), g.nimages), dim3(256), 0, s, plane_base, plane_carry, po);
 }
 
 }  // namespace felics

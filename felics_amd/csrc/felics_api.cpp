@@ -1,5 +1,5 @@
 // felics_api.cpp -- host side of libfelics: the C ABI of include/felics.h on top of the
-// gfx950 kernels.  One context = one GPU + one HIP stream + a grow-only workspace in HBM.
+// gfx950 kernels.  One context = one GPU + four HIP streams + a grow-only workspace in HBM.
 //
 // Encode is GPU-only by design: there is no CPU encode path in this library.
 #include <hip/hip_runtime.h>

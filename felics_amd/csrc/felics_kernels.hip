@@ -579,7 +579,9 @@ __global__ __launch_bounds__(256) void k_assign(const ET *__restrict__ sorted_e,
     const uint32_t lane = lane_id();
     const uint32_t nblocks = *total_slots >> 6;
     const uint32_t nwaves = gridDim.x * 4;
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // (wave-uniform, and said so: block indices, the blocks' records and the six counters then live in scalar
+    // registers and the halvings are scalar arithmetic)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     const uint4 *st = reinterpret_cast<const uint4 *>(block_state);
     // blocks resolved by this slice's spine launch
     for (uint32_t g0 = wave; g0 < nblocks; g0 += nwaves * 64) {

@@ -100,9 +100,10 @@ __global__ __launch_bounds__(256) void k_wide_chains(const uint32_t *__restrict_
                                                      const uint32_t *__restrict__ nheads, uint8_t *__restrict__ k_map) {
     const uint32_t lane = lane_id();
     const uint32_t nchains = *nheads;
-    const uint32_t wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t c = wave0; c < nchains; c += nwaves) {
-        uint32_t j = heads[c];
+        uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)heads[c]);  // wave-uniform: chain position and counters stay scalar
         const uint32_t key = keys[j];
         uint32_t S[WIDE_NK];
 #pragma unroll

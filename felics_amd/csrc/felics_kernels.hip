@@ -991,20 +991,22 @@ struct LaneBits {
     }
 };
 
+// One pixel's code.  Both kinds of code are built without branching -- `1` + phased-in
+// (compression.rs:131-134), or `00` below / `01` above (compression.rs:35-42), unary quotient, 0, k-bit
+// remainder -- and one of them is appended; only a Rice code longer than 32 bits takes a branch.
 template <typename BW>
 __device__ __forceinline__ void put_pixel(BW &bw, const PixelClass &pc, uint32_t k) {
-    if (pc.cls == CLS_IN) {  // `1` + phased-in (compression.rs:131-134)
-        uint32_t b, nb;
-        phase_in(pc.ctx + 1, pc.val, b, nb);
-        bw.put((1u << nb) | b, nb + 1);
-        return;
-    }
-    // `00` below / `01` above (compression.rs:35-42), unary quotient, 0, k-bit remainder
+    uint32_t b, nb;
+    phase_in(pc.ctx + 1, pc.val, b, nb);
+    const bool in_range = pc.cls == CLS_IN;
     const uint32_t flag = pc.cls == CLS_ABOVE ? 1u : 0u;
     const uint32_t q = pc.val >> k, rem = pc.val & ((1u << k) - 1u);
-    if (q + k + 3 <= 32) {
-        const uint32_t ones = q ? ((1u << q) - 1u) : 0u;  // q <= 29 here
-        bw.put((flag << (q + 1 + k)) | (ones << (k + 1)) | rem, q + k + 3);
+    const uint32_t n_rice = q + k + 3;
+    const uint32_t n = in_range ? nb + 1 : n_rice;
+    if (n <= 32) {
+        const uint32_t sh = q & 31u;  // (q <= 29 whenever the Rice code is the one used)
+        const uint32_t rice = (((flag << sh) | ((1u << sh) - 1u)) << (k + 1)) | rem;  // 0, flag, q ones, 0, rem
+        bw.put(in_range ? (1u << nb) | b : rice, n);
     } else {
         bw.put(flag, 2);
         bw.put_ones(q);

@@ -53,10 +53,12 @@ struct PixelClass {
 // Pixel p against its two neighbours' values (compression.rs:124-145).
 __device__ __forceinline__ PixelClass classify_values(int p, int v1, int v2) {
     const int H = max(v1, v2), L = min(v1, v2);
+    const int ctx = H - L, d = p - L;  // in range: 0 <= d <= ctx
     PixelClass r;
-    r.ctx = (uint32_t)(H - L);
-    r.cls = p < L ? CLS_BELOW : (p > H ? CLS_ABOVE : CLS_IN);
-    r.val = p < L ? (uint32_t)(L - p - 1) : (p > H ? (uint32_t)(p - H - 1) : (uint32_t)(p - L));
+    r.ctx = (uint32_t)ctx;
+    r.cls = d < 0 ? CLS_BELOW : (d > ctx ? CLS_ABOVE : CLS_IN);
+    // L - p - 1 = ~d ; p - H - 1 = d - ctx - 1
+    r.val = (uint32_t)(d < 0 ? ~d : (d > ctx ? d - ctx - 1 : d));
     return r;
 }
 

@@ -216,6 +216,40 @@ def test_pack_variants(oracle):
             e.close()
 
 
+def test_random_shapes_and_contents(enc, oracle):
+    """A few seconds of random geometry (1 pixel wide to 5000), content (noise, ramps, flat with full-scale
+    spikes, constant), sample type and batch size, every stream compared with the oracle."""
+    import time
+
+    rng = np.random.default_rng(77)
+
+    def content(h, w, c, dt, kind):
+        mx = 255 if dt == np.uint8 else 65535
+        shape = (h, w) if c == 1 else (h, w, 3)
+        if kind == 0:
+            return rng.integers(0, mx + 1, size=shape).astype(dt)
+        if kind == 1:
+            base = np.add.outer(np.arange(h) * 3, np.arange(w) * 2) % (mx + 1)
+            img = base if c == 1 else np.stack([base, base[::-1], (base * 7) % (mx + 1)], -1)
+            return (img + rng.integers(0, 4, size=shape)).clip(0, mx).astype(dt)
+        if kind == 2:
+            img = np.full(shape, mx // 3, dtype=np.int64) + rng.integers(0, 2, size=shape)
+            n = max(1, h * w // 50)
+            img[rng.integers(0, h, n), rng.integers(0, w, n)] = rng.choice([0, mx], size=(n,) if c == 1 else (n, 3))
+            return img.astype(dt)
+        return np.full(shape, rng.integers(0, mx + 1), dtype=dt)
+
+    t0, batches = time.time(), 0
+    while time.time() - t0 < 8.0:
+        w = int(rng.choice([rng.integers(1, 40), rng.integers(1, 700), rng.integers(1000, 5000)]))
+        h = int(rng.choice([rng.integers(1, 40), rng.integers(1, 300)]))
+        c, dt = int(rng.choice([1, 3])), rng.choice([np.uint8, np.uint8, np.uint16])
+        frames = [content(h, w, c, dt, int(rng.integers(0, 4))) for _ in range(int(rng.integers(1, 10)))]
+        assert enc.compress_batch(frames) == [oracle.compress(f) for f in frames], (w, h, c, dt, len(frames))
+        batches += 1
+    assert batches > 20
+
+
 def test_errors(enc):
     import felics_amd
 

@@ -89,6 +89,31 @@ __device__ __forceinline__ PixelClass classify_interior(const T *__restrict__ pl
     return classify_values((int)pl[i], (int)pl[i - 1], (int)pl[i - W]);
 }
 
+// Four consecutive samples with one (possibly unaligned) 4- or 8-byte load.
+__device__ __forceinline__ void load4(const uint8_t *__restrict__ p, int (&v)[4]) {
+    uint32_t w;
+    __builtin_memcpy(&w, p, 4);
+    v[0] = (int)(w & 0xFFu); v[1] = (int)((w >> 8) & 0xFFu); v[2] = (int)((w >> 16) & 0xFFu); v[3] = (int)(w >> 24);
+}
+__device__ __forceinline__ void load4(const int16_t *__restrict__ p, int (&v)[4]) {
+    uint32_t w[2];
+    __builtin_memcpy(w, p, 8);
+    v[0] = (int)(int16_t)w[0]; v[1] = (int)w[0] >> 16; v[2] = (int)(int16_t)w[1]; v[3] = (int)w[1] >> 16;
+}
+
+// Interior pixels i .. i + 3 of one image row (x > 0, y > 0 for all four): left and above, from two wide
+// loads plus the sample left of the first one (`left0`).
+template <typename T>
+__device__ __forceinline__ void classify_interior4(const T *__restrict__ pl, uint32_t i, uint32_t W, int left0,
+                                                   PixelClass (&pc)[4]) {
+    int cur[4], up[4];
+    load4(pl + i, cur);
+    load4(pl + i - W, up);
+    pc[0] = classify_values(cur[0], left0, up[0]);
+#pragma unroll
+    for (int j = 1; j < 4; j++) pc[j] = classify_values(cur[j], cur[j - 1], up[j]);
+}
+
 // (x, y) of linear index i; advance() moves forward by `step` pixels without dividing again.
 struct Coord {
     uint32_t x, y;

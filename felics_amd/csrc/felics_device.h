@@ -101,14 +101,18 @@ __device__ __forceinline__ void load4(const int16_t *__restrict__ p, int (&v)[4]
     v[0] = (int)(int16_t)w[0]; v[1] = (int)w[0] >> 16; v[2] = (int)(int16_t)w[1]; v[3] = (int)w[1] >> 16;
 }
 
-// Interior pixels i .. i + 3 of one image row (x > 0, y > 0 for all four): left and above, from two wide
-// loads plus the sample left of the first one (`left0`).
+// Interior pixels of one image row (x > 0, y > 0 for all), four per lane: left and above from two wide loads.
+// A wave covers 256 consecutive pixels (lane l: first + 4l ..), so the sample left of a lane's first pixel
+// is the last sample of the lane before it (one DPP wave shift); lane 0 fetches its own.
 template <typename T>
-__device__ __forceinline__ void classify_interior4(const T *__restrict__ pl, uint32_t i, uint32_t W, int left0,
+__device__ __forceinline__ void classify_interior4(const T *__restrict__ pl, uint32_t first, uint32_t W,
                                                    PixelClass (&pc)[4]) {
+    const uint32_t i = first + 4 * lane_id();
     int cur[4], up[4];
     load4(pl + i, cur);
     load4(pl + i - W, up);
+    int left0 = __builtin_amdgcn_update_dpp(0, cur[3], 0x138, 0xF, 0xF, false);  // wave_shr:1
+    if (lane_id() == 0) left0 = (int)pl[first - 1];
     pc[0] = classify_values(cur[0], left0, up[0]);
 #pragma unroll
     for (int j = 1; j < 4; j++) pc[j] = classify_values(cur[j], cur[j - 1], up[j]);

@@ -79,8 +79,7 @@ __global__ __launch_bounds__(256) void k_hist(const T *__restrict__ planes, uint
             if (interior) {
                 // lane l takes pixels r0 + 4l .. + 3: two wide loads instead of twelve byte loads (counting
                 // does not care which lane sees which pixel)
-                const uint32_t i = r0 + 4 * lane;
-                classify_interior4(pl, i, W, (int)pl[i - 1], pc);
+                classify_interior4(pl, r0, W, pc);
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++) ev[u] = pc[u].cls != CLS_IN;
             } else {
@@ -274,7 +273,7 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
             // sum of the lanes' event counts keeps the ring in raster order
             const uint32_t off0 = row0 - begin + 4 * lane;
             PixelClass pc[4];
-            classify_interior4(pl, row0 + 4 * lane, W, (int)pl[row0 + 4 * lane - 1], pc);
+            classify_interior4(pl, row0, W, pc);
             uint32_t nev = 0;
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) nev += pc[j].cls != CLS_IN ? 1u : 0u;

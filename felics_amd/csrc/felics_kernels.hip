@@ -115,18 +115,39 @@ __global__ __launch_bounds__(256) void k_hist(const T *__restrict__ planes, uint
 
 // ------------------------------------------------------------------------------------------
 // offsets: per (plane, ctx) exclusive scan over tiles (in place), chain length out.
-// One thread per (plane, ctx); lanes run over ctx so every step is a coalesced row access.
+// A workgroup takes 32 contexts of a plane; the tiles are cut into 8 segments, thread (seg, ctx) sums its
+// segment, the segment totals are exchanged through LDS, and the segment is walked again writing the
+// running offsets.  Lanes run over ctx, so every step is a coalesced 128-byte access; eight loads are in
+// flight per thread.
 // ------------------------------------------------------------------------------------------
 
-__global__ void k_tile_offsets(uint32_t *__restrict__ counts, uint32_t *__restrict__ chain_len,
-                               uint32_t nplanes, uint32_t ntiles) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nplanes * NCTX) return;
-    uint32_t plane = g / NCTX, c = g - plane * NCTX;
+constexpr uint32_t OFF_SEGS = 8, OFF_CTX = 32;
+
+__global__ __launch_bounds__(OFF_SEGS *OFF_CTX) void k_tile_offsets(uint32_t *__restrict__ counts,
+                                                                    uint32_t *__restrict__ chain_len, uint32_t ntiles) {
+    __shared__ uint32_t seg_sum[OFF_SEGS][OFF_CTX];
+    const uint32_t cl = threadIdx.x % OFF_CTX, seg = threadIdx.x / OFF_CTX;
+    const uint32_t plane = blockIdx.y, c = blockIdx.x * OFF_CTX + cl;
+    const uint32_t per = (ntiles + OFF_SEGS - 1) / OFF_SEGS;
+    const uint32_t t0 = min(seg * per, ntiles), t1 = min(t0 + per, ntiles);
     uint32_t *col = counts + (uint64_t)plane * ntiles * NCTX + c;
+    uint32_t sum = 0;
+    uint32_t t = t0;
+    for (; t + 8 <= t1; t += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) v[u] = col[(uint64_t)(t + u) * NCTX];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) sum += v[u];
+    }
+    for (; t < t1; t++) sum += col[(uint64_t)t * NCTX];
+    seg_sum[seg][cl] = sum;
+    __syncthreads();
     uint32_t run = 0;
-    uint32_t t = 0;
-    for (; t + 8 <= ntiles; t += 8) {  // eight independent loads in flight, then the running sum
+    for (uint32_t q = 0; q < seg; q++) run += seg_sum[q][cl];
+    if (seg == OFF_SEGS - 1) chain_len[plane * NCTX + c] = run + sum;
+    t = t0;
+    for (; t + 8 <= t1; t += 8) {  // eight independent loads in flight, then the running sum
         uint32_t v[8];
 #pragma unroll
         for (uint32_t u = 0; u < 8; u++) v[u] = col[(uint64_t)(t + u) * NCTX];
@@ -136,12 +157,11 @@ __global__ void k_tile_offsets(uint32_t *__restrict__ counts, uint32_t *__restri
             run += v[u];
         }
     }
-    for (; t < ntiles; t++) {
-        uint32_t v = col[(uint64_t)t * NCTX];
+    for (; t < t1; t++) {
+        const uint32_t v = col[(uint64_t)t * NCTX];
         col[(uint64_t)t * NCTX] = run;
         run += v;
     }
-    chain_len[g] = run;
 }
 
 // Exclusive scan of the chain lengths, each rounded up to a whole 64-event block, over all
@@ -1456,7 +1476,7 @@ template void launch_hist<int16_t>(hipStream_t, const int16_t *, uint32_t *, con
 void launch_offsets(hipStream_t s, uint32_t *counts, uint32_t *chain_len, uint32_t *chain_base,
                     uint32_t *total_events, const Geometry &g) {
     const uint32_t nchains = g.nplanes * NCTX;
-    hipLaunchKernelGGL(k_tile_offsets, dim3(cdiv(nchains, 256)), dim3(256), 0, s, counts, chain_len, g.nplanes,
+    hipLaunchKernelGGL(k_tile_offsets, dim3(NCTX / OFF_CTX, g.nplanes), dim3(OFF_SEGS * OFF_CTX), 0, s, counts, chain_len,
                        g.sort_tiles);
     hipLaunchKernelGGL(k_chain_bases, dim3(1), dim3(1024), 0, s, chain_len, chain_base, nchains, total_events);
 }

@@ -10,10 +10,13 @@
 //   scatter  stable partition of the events by context, raster order kept
 //   resolve  replay the Rice-parameter estimator along every chain
 //            (parameter_selection.rs:49-85): spine (sequential, per chain) + assign (parallel)
-//   lengths  code length of every pixel -> bits per tile
-//   bitscan  exclusive scan of tile bits -> bit offset of every tile in its stream
 //   pack     build the codes (rice_coding.rs:26-38, phase_in_coding.rs:59-84,
-//            compression.rs:29-45) and pack them MSB-first (bitstream-io BigEndian)
+//            compression.rs:29-45) and pack them MSB-first (bitstream-io BigEndian).
+//            Single pass (k_pack_fused: code lengths, tile offsets by decoupled look-back, packing),
+//            or two passes for exact placement / 16-bit samples / as a fallback:
+//   lengths    code length of every pixel -> bits per tile
+//   bitscan    exclusive scan of tile bits -> bit offset of every tile in its stream
+//   pack       the codes again, packed at those offsets
 //
 // Integer work only: no MFMA.  Wave = 64 lanes everywhere.
 #include <hip/hip_runtime.h>

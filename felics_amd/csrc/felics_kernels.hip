@@ -32,23 +32,51 @@ namespace felics {
 // `/ 2` on int truncates toward zero exactly like Rust's.
 // ------------------------------------------------------------------------------------------
 
-__global__ void k_rgb8_to_planes(const uint8_t *__restrict__ rgb, int16_t *__restrict__ planes,
-                                 uint32_t npix, uint32_t nimg) {
-    uint64_t total = (uint64_t)npix * nimg;
+__device__ __forceinline__ void ycocg(int r, int gr, int b, int &yv, int &co, int &cg) {
+    co = r - b;
+    const int t = b + co / 2;
+    cg = gr - t;
+    yv = t + cg / 2;
+}
+
+// Four pixels per thread: 12 bytes in (three dwords), four samples out per plane (one 8-byte store each).
+// A group never straddles two images (it starts at a multiple of four inside its image; the last pixels
+// of an image whose size is not a multiple of four take the single-pixel path).
+__global__ __launch_bounds__(256) void k_rgb8_to_planes(const uint8_t *__restrict__ rgb, int16_t *__restrict__ planes,
+                                                        uint32_t npix, uint32_t nimg) {
+    const uint32_t groups = (npix + 3) / 4;  // per image
+    const uint64_t total = (uint64_t)groups * nimg;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
          g += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t img = (uint32_t)(g / npix);
-        uint32_t i = (uint32_t)(g - (uint64_t)img * npix);
-        const uint8_t *s = rgb + g * 3;
-        int r = s[0], gr = s[1], b = s[2];
-        int co = r - b;
-        int t = b + co / 2;
-        int cg = gr - t;
-        int yv = t + cg / 2;
+        const uint32_t img = (uint32_t)(g / groups);
+        const uint32_t i = (uint32_t)(g - (uint64_t)img * groups) * 4;
+        const uint8_t *src = rgb + ((uint64_t)img * npix + i) * 3;
         int16_t *o = planes + (uint64_t)img * 3 * npix;
-        o[i] = (int16_t)yv;
-        o[(uint64_t)npix + i] = (int16_t)co;
-        o[2ull * npix + i] = (int16_t)cg;
+        if (i + 4 <= npix) {
+            uint32_t w[3];
+            __builtin_memcpy(w, src, 12);
+            int yv[4], co[4], cg[4];
+            ycocg((int)(w[0] & 0xFFu), (int)((w[0] >> 8) & 0xFFu), (int)((w[0] >> 16) & 0xFFu), yv[0], co[0], cg[0]);
+            ycocg((int)(w[0] >> 24), (int)(w[1] & 0xFFu), (int)((w[1] >> 8) & 0xFFu), yv[1], co[1], cg[1]);
+            ycocg((int)((w[1] >> 16) & 0xFFu), (int)(w[1] >> 24), (int)(w[2] & 0xFFu), yv[2], co[2], cg[2]);
+            ycocg((int)((w[2] >> 8) & 0xFFu), (int)((w[2] >> 16) & 0xFFu), (int)(w[2] >> 24), yv[3], co[3], cg[3]);
+            auto put4 = [&](int16_t *dst, const int (&v)[4]) {
+                const uint32_t p[2] = {(uint32_t)(v[0] & 0xFFFF) | ((uint32_t)v[1] << 16),
+                                       (uint32_t)(v[2] & 0xFFFF) | ((uint32_t)v[3] << 16)};
+                __builtin_memcpy(dst, p, 8);
+            };
+            put4(o + i, yv);
+            put4(o + (uint64_t)npix + i, co);
+            put4(o + 2ull * npix + i, cg);
+        } else {
+            for (uint32_t j = i; j < npix; j++) {
+                int yv, co, cg;
+                ycocg(src[(j - i) * 3], src[(j - i) * 3 + 1], src[(j - i) * 3 + 2], yv, co, cg);
+                o[j] = (int16_t)yv;
+                o[(uint64_t)npix + j] = (int16_t)co;
+                o[2ull * npix + j] = (int16_t)cg;
+            }
+        }
     }
 }
 
@@ -1462,7 +1490,7 @@ __global__ __launch_bounds__(256) void k_concat_planes(const uint64_t *__restric
 static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 void launch_rgb8_to_planes(hipStream_t s, const uint8_t *rgb, int16_t *planes, uint32_t npix, uint32_t nimg) {
-    uint64_t total = (uint64_t)npix * nimg;
+    uint64_t total = (uint64_t)((npix + 3) / 4) * nimg;  // four pixels per thread
     uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256u * 32u);
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_rgb8_to_planes, dim3(blocks), dim3(256), 0, s, rgb, planes, npix, nimg);

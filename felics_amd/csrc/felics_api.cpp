@@ -514,6 +514,8 @@ void collect_timing(felics_ctx *ctx) {
 size_t max_images_per_pass(uint64_t npix, uint32_t planes, int depth) {
     const uint64_t per_image = npix * planes;
     if (per_image == 0) return SIZE_MAX;
+    if (const char *e = getenv("FELICS_TEST_PASS_IMAGES"))  // tests: several passes without a 100 GB batch
+        return (size_t)std::max(1, atoi(e));
     if (depth == FELICS_DEPTH_16)  // ~29 bytes of workspace per sample: keep a pass near 2^30 samples
         return (size_t)std::max<uint64_t>(1, std::min<uint64_t>(0x40000000ull / per_image, WIDE_MAX_PLANES / planes));
     return (size_t)std::max<uint64_t>(1, 0xE0000000ull / (per_image + 64ull * planes * NCTX));

@@ -250,6 +250,31 @@ def test_random_shapes_and_contents(enc, oracle):
     assert batches > 20
 
 
+def test_several_passes(oracle):
+    """A batch larger than one pass holds (FELICS_TEST_PASS_IMAGES caps the pass instead of a 400-frame 4K
+    batch): host-pointer and device entry points, gray / RGB / 16-bit."""
+    import felics_amd
+    import torch
+    from felics_amd import synth
+
+    os.environ["FELICS_TEST_PASS_IMAGES"] = "3"
+    try:
+        with felics_amd.Encoder(0) as e:
+            for frames in ([synth.gray8(640, 480, f, "S1") for f in range(10)], [synth.rgb8(320, 240, f) for f in range(7)],
+                           [synth.gray16(320, 240, f) for f in range(8)]):
+                assert e.compress_batch(frames) == [oracle.compress(f) for f in frames]
+            frames = [synth.gray8(1024, 512, f, "S1") for f in range(11)]
+            d_in = torch.from_numpy(np.stack(frames)).cuda()
+            d_out = torch.zeros(11 * 1024 * 512 * 2, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            offs, lens = e.compress_batch_device(d_in.data_ptr(), 11, 1024, 512, 0, 0, d_out.data_ptr(), d_out.numel())
+            host = d_out.cpu().numpy()
+            for i, f in enumerate(frames):
+                assert host[int(offs[i]): int(offs[i] + lens[i])].tobytes() == oracle.compress(f)
+    finally:
+        del os.environ["FELICS_TEST_PASS_IMAGES"]
+
+
 def test_errors(enc):
     import felics_amd
 

@@ -186,6 +186,28 @@ def test_sixteen_bit_content(enc, oracle):
     assert enc.compress_batch(rgb) == [oracle.compress(f) for f in rgb]
 
 
+def test_sixteen_bit_exact_placement(enc, oracle):
+    """16-bit and RGB through the device entry point with a buffer too small for fixed slots: the streams are
+    placed back to back (two-pass pack, exact placement)."""
+    import torch
+    from felics_amd import synth
+
+    for frames, color, depth in (([synth.gray16(512, 384, f) for f in range(5)], 0, 1),
+                                 ([synth.rgb8(512, 384, f) for f in range(5)], 1, 0)):
+        flat = np.random.default_rng(3).integers(0, 3, size=frames[0].shape).astype(frames[0].dtype)
+        frames = frames[:2] + [flat] + frames[2:]  # one small stream among big ones
+        want = [oracle.compress(f) for f in frames]
+        cap = sum((len(x) + 15) // 16 * 16 for x in want) + 64
+        d_in = torch.from_numpy(np.stack(frames).view(np.uint8)).cuda()
+        d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        offs, lens = enc.compress_batch_device(d_in.data_ptr(), len(frames), 512, 384, color, depth, d_out.data_ptr(), cap)
+        host = d_out.cpu().numpy()
+        assert list(offs) == sorted(offs) and all(int(o) % 16 == 0 for o in offs)
+        for i, x in enumerate(want):
+            assert host[int(offs[i]): int(offs[i] + lens[i])].tobytes() == x, i
+
+
 def test_sixteen_bit_4k(enc, oracle):
     from felics_amd import synth
 

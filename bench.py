@@ -188,6 +188,14 @@ def main():
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(per_launch_ms, 4),
                         "launches_per_step": launches}
+        # the same figure for every stage (HIP-event brackets; on the low-priority streams they include the wait
+        # for free compute resources, which rocprof's kernel begin / end timestamps do not)
+        per_stage = {}
+        for k, v in stage_ms.items():
+            n = max(1, enc.stage_launches().get(k, 1))
+            if v > 0:
+                per_stage["k_" + k] = {"avg_launch_ms": round(v / n, 4), "launches_per_step": n,
+                                       "achieved_GBs": round(alg_bytes / n / (v / n * 1e-3) / 1e9, 2)}
         pipeline_gbs = alg_bytes / (ms_per_step * 1e-3) / 1e9
         cpu1 = cpum = None
         if args.cpu_seconds > 0:
@@ -211,6 +219,7 @@ def main():
             "cpu_baseline_all_cores": cpum,
             "pipeline": {"achieved_GBs": round(pipeline_gbs, 2), "frac_of_hbm_peak": round(pipeline_gbs / HBM_PEAK_GBS, 5),
                          "stage_ms_sum_of_launches": {k: round(v, 4) for k, v in stage_ms.items()},
+                         "per_stage": per_stage,
                          "note": "the stages follow each other slice by slice on four HIP streams; launches overlap, so the sums exceed ms_per_step"},
             "parity": {"frames_byte_compared_with_oracle": checked, "output_checksum_stable": True,
                        "compressed_bytes_per_step_rank0": total_bytes,

@@ -160,14 +160,26 @@ struct StageTimer {
     int st;
     hipStream_t stream;
     int slot = -1;
-    StageTimer(felics_ctx *c, Lane &l, int s, hipStream_t on) : ctx(c), lane(l), st(s), stream(on) {
+    bool exact;  // one kernel launch inside: record that kernel's own begin / end (see LaunchTiming)
+    StageTimer(felics_ctx *c, Lane &l, int s, hipStream_t on, bool single_kernel = false)
+        : ctx(c), lane(l), st(s), stream(on), exact(single_kernel) {
         if (ctx->profiling && lane.ev_used[st] < EV_PAIRS) {
             slot = lane.ev_used[st]++;
-            (void)hipEventRecord(lane.ev[st][slot][0], stream);
+            if (exact)
+                g_launch_timing = LaunchTiming{lane.ev[st][slot][0], lane.ev[st][slot][1]};
+            else
+                (void)hipEventRecord(lane.ev[st][slot][0], stream);
         }
     }
     ~StageTimer() {
-        if (slot >= 0) (void)hipEventRecord(lane.ev[st][slot][1], stream);
+        if (slot >= 0) {
+            if (!exact) {
+                (void)hipEventRecord(lane.ev[st][slot][1], stream);
+            } else if (g_launch_timing.start) {  // nothing was launched: give the pair back
+                g_launch_timing = LaunchTiming{};
+                lane.ev_used[st]--;
+            }
+        }
         if (ctx->trace) {  // FELICS_TRACE: wait for the stage and say so (locating a kernel that does not return)
             hipError_t e = hipStreamSynchronize(stream);
             fprintf(stderr, "[felics] %s done (%s)\n", kStageNames[st], hipGetErrorString(e));
@@ -277,7 +289,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
             if (b->p) HIP_TRY(ctx, hipMemsetAsync(b->p, 0xA5, b->cap, f));
     }
     {
-        StageTimer t(ctx, l, ST_HIST, f);
+        StageTimer t(ctx, l, ST_HIST, f, true);
         launch_hist<T>(f, d_planes, counts, g);
     }
     {
@@ -294,7 +306,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     }
     for (int q = 0; q < SLICES; q++) {
         if (bounds[q + 1] != bounds[q]) {
-            StageTimer t(ctx, l, ST_SCATTER, f);
+            StageTimer t(ctx, l, ST_SCATTER, f, true);
             launch_scatter<T, ET>(f, d_planes, counts, chain_base, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, g,
                                   bounds[q], bounds[q + 1]);
         }
@@ -304,7 +316,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     for (int q = 0; q < SLICES; q++) {
         HIP_TRY(ctx, hipStreamWaitEvent(s, l.slice_done[q], 0));
         if (bounds[q + 1] != bounds[q] || q + 1 == SLICES) {
-            StageTimer t(ctx, l, ST_SPINE, s);
+            StageTimer t(ctx, l, ST_SPINE, s, true);
             launch_spine<ET>(s, (const ET *)l.sorted_e.p, (uint32_t *)l.block_state.p, chain_base, chain_len, counts,
                              bounds[q + 1], chain_prog, (uint32_t *)l.block_tag.p, (uint32_t *)l.partial.p, epoch,
                              (uint32_t)q + 1, g);
@@ -315,7 +327,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     for (int q = 0; q < SLICES; q++) {
         HIP_TRY(ctx, hipStreamWaitEvent(ks, l.spine_done[q], 0));
         if (bounds[q + 1] != bounds[q] || q + 1 == SLICES) {
-            StageTimer t(ctx, l, ST_ASSIGN, ks);
+            StageTimer t(ctx, l, ST_ASSIGN, ks, true);
             launch_assign<ET>(ks, (const ET *)l.sorted_e.p, (const uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
                               (const uint32_t *)l.block_state.p, (const uint32_t *)l.scalars.p,
                               (const uint32_t *)l.block_tag.p, (const uint32_t *)l.partial.p, epoch, (uint32_t)q + 1, g);
@@ -331,7 +343,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         if (bounds[q + 1] == bounds[q] && !last) continue;
         if (fused) {
             {
-                StageTimer t(ctx, l, ST_PACK, tl);
+                StageTimer t(ctx, l, ST_PACK, tl, true);
                 launch_pack_fused<T>(tl, d_planes, (const uint8_t *)l.k_map.p, (uint64_t *)l.status.p,
                                      (uint64_t *)l.tile_bitoff.p, (uint32_t *)l.tile_bits.p, plane_carry,
                                      (uint32_t *)l.edge_first.p, (uint32_t *)l.edge_last.p, d_error, target, g, pbounds[q],
@@ -347,7 +359,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
             continue;
         }
         {
-            StageTimer t(ctx, l, ST_LENGTHS, tl);
+            StageTimer t(ctx, l, ST_LENGTHS, tl, true);
             launch_lengths<T>(tl, d_planes, (const uint8_t *)l.k_map.p, (uint16_t *)l.group_bits.p,
                               (uint32_t *)l.tile_bits.p, g, pbounds[q], pbounds[q + 1]);
         }
@@ -365,7 +377,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
                                   (const uint32_t *)l.tile_bits.p, plane_base, g, t0, t1);
             }
             {
-                StageTimer t(ctx, l, ST_PACK, tl);
+                StageTimer t(ctx, l, ST_PACK, tl, true);
                 launch_pack<T>(tl, d_planes, (const uint8_t *)l.k_map.p, (const uint16_t *)l.group_bits.p,
                                (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p, plane_base, nullptr,
                                slot_stride, d_out, g, t0, t1);
@@ -426,7 +438,7 @@ int run_wide(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     }
     uint32_t *skeys = nullptr, *svals = nullptr;
     {
-        StageTimer t(ctx, l, ST_WIDE_KEYS, s);
+        StageTimer t(ctx, l, ST_WIDE_KEYS, s, true);
         launch_wide_keys<T>(s, d_planes, (uint32_t *)l.wkeys[0].p, (uint32_t *)l.wvals[0].p, (uint32_t *)l.e_of.p, g);
     }
     {
@@ -443,7 +455,7 @@ int run_wide(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     }
     HIP_TRY(ctx, hipMemsetAsync(plane_carry, 0, (size_t)g.nplanes * 16, s));
     {
-        StageTimer t(ctx, l, ST_LENGTHS, s);
+        StageTimer t(ctx, l, ST_LENGTHS, s, true);
         launch_lengths<T>(s, d_planes, (const uint8_t *)l.k_map.p, (group_bits_t<T> *)l.group_bits.p,
                           (uint32_t *)l.tile_bits.p, g, 0, g.pack_tiles);
     }
@@ -460,7 +472,7 @@ int run_wide(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
                               (const uint32_t *)l.tile_bits.p, plane_base, g, 0, g.pack_tiles);
         }
         {
-            StageTimer t(ctx, l, ST_PACK, s);
+            StageTimer t(ctx, l, ST_PACK, s, true);
             launch_pack<T>(s, d_planes, (const uint8_t *)l.k_map.p, (const group_bits_t<T> *)l.group_bits.p,
                            (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p, plane_base, nullptr,
                            slot_stride, d_out, g, 0, g.pack_tiles);
@@ -485,7 +497,7 @@ int pack_exact(felics_ctx *ctx, Lane &l, uint8_t *d_out) {
         launch_zero_streams(s, (uint32_t *)d_out, (const uint64_t *)l.image_off.p, g);
     }
     {
-        StageTimer t(ctx, l, ST_PACK, s);
+        StageTimer t(ctx, l, ST_PACK, s, true);
         launch_pack<T>(s, (const T *)l.d_planes, (const uint8_t *)l.k_map.p, (const group_bits_t<T> *)l.group_bits.p,
                        (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p, plane_base,
                        (const uint64_t *)l.image_off.p, 0, d_out, g, 0, g.pack_tiles);
@@ -614,7 +626,7 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
                 if (planes == 3) {
                     if ((rc = reserve(ctx, l.planes, (size_t)g.nplanes * npix * (wide ? 4 : 2) + STAGE_PAD)) != 0) return rc;
                     hipStream_t fs = wide || getenv("FELICS_SERIAL") ? l.stream : l.front;
-                    StageTimer t(ctx, l, ST_PLANES, fs);
+                    StageTimer t(ctx, l, ST_PLANES, fs, true);
                     if (wide)
                         launch_rgb16_to_planes(fs, (const uint16_t *)src, (int32_t *)l.planes.p, g.npix, g.nimages);
                     else

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <algorithm>
@@ -27,6 +28,25 @@ template <typename T> struct GroupBits { using type = uint16_t; };
 template <> struct GroupBits<uint16_t> { using type = uint32_t; };
 template <> struct GroupBits<int32_t> { using type = uint32_t; };
 template <typename T> using group_bits_t = typename GroupBits<T>::type;
+
+// Profiling: the host pipeline sets g_launch_timing around ONE launch to have that kernel's own begin and
+// end recorded in the two events (hipExtLaunchKernel: the dispatch's timestamps, what rocprofv3 reports),
+// instead of bracketing the launch with event records, which also measure the launch's wait for free
+// compute resources.  The launcher that consumes it clears it.
+struct LaunchTiming {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+extern thread_local LaunchTiming g_launch_timing;
+
+#define FELICS_LAUNCH(KERNEL, GRID, BLOCK, STREAM, ...)                                                    \
+    do {                                                                                                   \
+        const ::felics::LaunchTiming lt_ = ::felics::g_launch_timing;                                      \
+        ::felics::g_launch_timing = ::felics::LaunchTiming{};                                              \
+        if (lt_.start)                                                                                     \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, STREAM, lt_.start, lt_.stop, 0, __VA_ARGS__);   \
+        else                                                                                               \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, STREAM, __VA_ARGS__);                               \
+    } while (0)
 
 struct Geometry {
     uint32_t W, H;

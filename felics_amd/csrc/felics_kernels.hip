@@ -27,6 +27,8 @@
 
 namespace felics {
 
+thread_local LaunchTiming g_launch_timing;
+
 // ------------------------------------------------------------------------------------------
 // planes: interleaved RGB8 -> three int16 planes Y, Co, Cg (color_transform.rs:11-17).
 // `/ 2` on int truncates toward zero exactly like Rust's.
@@ -1493,12 +1495,12 @@ void launch_rgb8_to_planes(hipStream_t s, const uint8_t *rgb, int16_t *planes, u
     uint64_t total = (uint64_t)((npix + 3) / 4) * nimg;  // four pixels per thread
     uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256u * 32u);
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_rgb8_to_planes, dim3(blocks), dim3(256), 0, s, rgb, planes, npix, nimg);
+    FELICS_LAUNCH(k_rgb8_to_planes, dim3(blocks), dim3(256), s, rgb, planes, npix, nimg);
 }
 
 template <typename T>
 void launch_hist(hipStream_t s, const T *planes, uint32_t *counts, const Geometry &g) {
-    hipLaunchKernelGGL((k_hist<T>), dim3(cdiv(g.sort_tiles, 4), g.nplanes), dim3(256), 0, s, planes, counts, g.W,
+    FELICS_LAUNCH((k_hist<T>), dim3(cdiv(g.sort_tiles, 4), g.nplanes), dim3(256), s, planes, counts, g.W,
                        g.npix, g.sort_tiles);
 }
 template void launch_hist<uint8_t>(hipStream_t, const uint8_t *, uint32_t *, const Geometry &);
@@ -1507,16 +1509,16 @@ template void launch_hist<int16_t>(hipStream_t, const int16_t *, uint32_t *, con
 void launch_offsets(hipStream_t s, uint32_t *counts, uint32_t *chain_len, uint32_t *chain_base,
                     uint32_t *total_events, const Geometry &g) {
     const uint32_t nchains = g.nplanes * NCTX;
-    hipLaunchKernelGGL(k_tile_offsets, dim3(NCTX / OFF_CTX, g.nplanes), dim3(OFF_SEGS * OFF_CTX), 0, s, counts, chain_len,
+    FELICS_LAUNCH(k_tile_offsets, dim3(NCTX / OFF_CTX, g.nplanes), dim3(OFF_SEGS * OFF_CTX), s, counts, chain_len,
                        g.sort_tiles);
-    hipLaunchKernelGGL(k_chain_bases, dim3(1), dim3(1024), 0, s, chain_len, chain_base, nchains, total_events);
+    FELICS_LAUNCH(k_chain_bases, dim3(1), dim3(1024), s, chain_len, chain_base, nchains, total_events);
 }
 
 template <typename T, typename ET>
 void launch_scatter(hipStream_t s, const T *planes, const uint32_t *tile_off, const uint32_t *chain_base,
                     ET *sorted_e, uint32_t *pix_of, const Geometry &g, uint32_t tile_begin, uint32_t tile_end) {
     if (tile_end <= tile_begin) return;
-    hipLaunchKernelGGL((k_scatter<T, ET>), dim3(cdiv(tile_end - tile_begin, 4), g.nplanes), dim3(256), 0, s, planes,
+    FELICS_LAUNCH((k_scatter<T, ET>), dim3(cdiv(tile_end - tile_begin, 4), g.nplanes), dim3(256), s, planes,
                        tile_off, chain_base, sorted_e, pix_of, g.W, g.npix, g.sort_tiles, tile_begin, tile_end);
 }
 template void launch_scatter<uint8_t, uint8_t>(hipStream_t, const uint8_t *, const uint32_t *, const uint32_t *,
@@ -1528,7 +1530,7 @@ template <typename ET>
 void launch_zero_padding(hipStream_t s, ET *sorted_e, uint32_t *pix_of, const uint32_t *chain_base,
                          const uint32_t *chain_len, const Geometry &g) {
     const uint32_t nchains = g.nplanes * NCTX;
-    hipLaunchKernelGGL((k_zero_padding<ET>), dim3(cdiv(nchains, 256)), dim3(256), 0, s, sorted_e, pix_of, chain_base,
+    FELICS_LAUNCH((k_zero_padding<ET>), dim3(cdiv(nchains, 256)), dim3(256), s, sorted_e, pix_of, chain_base,
                        chain_len, nchains);
 }
 template void launch_zero_padding<uint8_t>(hipStream_t, uint8_t *, uint32_t *, const uint32_t *, const uint32_t *,
@@ -1541,7 +1543,7 @@ void launch_spine(hipStream_t s, const ET *sorted_e, uint32_t *block_state, cons
                   const uint32_t *chain_len, const uint32_t *tile_off, uint32_t t_end, uint32_t *chain_prog,
                   uint32_t *block_tag, uint32_t *partial, uint32_t epoch, uint32_t slice, const Geometry &g) {
     const uint32_t nchains = g.nplanes * NCTX;
-    hipLaunchKernelGGL((k_spine<ET>), dim3(nchains), dim3(64), 0, s, sorted_e, block_state, chain_base, chain_len,
+    FELICS_LAUNCH((k_spine<ET>), dim3(nchains), dim3(64), s, sorted_e, block_state, chain_base, chain_len,
                        nchains, tile_off, g.sort_tiles, t_end, chain_prog, block_tag,
                        reinterpret_cast<uint2 *>(partial) + (uint64_t)(slice - 1) * nchains,
                        (epoch << TAG_SLICE_BITS) | slice);
@@ -1561,7 +1563,7 @@ void launch_assign(hipStream_t s, const ET *sorted_e, const uint32_t *pix_of, ui
     const uint32_t nchains = g.nplanes * NCTX;
     const uint32_t max_blocks = max_event_blocks(g);
     const uint32_t wgs = std::min<uint32_t>(cdiv(max_blocks, 4 * 64), 256u * 8u);
-    hipLaunchKernelGGL((k_assign<ET>), dim3(wgs), dim3(256), 0, s, sorted_e, block_state, pix_of, k_map, total_slots,
+    FELICS_LAUNCH((k_assign<ET>), dim3(wgs), dim3(256), s, sorted_e, block_state, pix_of, k_map, total_slots,
                        block_tag, reinterpret_cast<const uint2 *>(partial) + (uint64_t)(slice - 1) * nchains, nchains,
                        (epoch << TAG_SLICE_BITS) | slice);
 }
@@ -1576,7 +1578,7 @@ template <typename T>
 void launch_lengths(hipStream_t s, const T *planes, const uint8_t *k_map, group_bits_t<T> *group_bits,
                     uint32_t *tile_bits, const Geometry &g, uint32_t t0, uint32_t t1) {
     if (t1 <= t0) return;
-    hipLaunchKernelGGL((k_lengths<T>), dim3(t1 - t0, g.nplanes), dim3(PACK_THREADS), 0, s, planes, k_map, group_bits,
+    FELICS_LAUNCH((k_lengths<T>), dim3(t1 - t0, g.nplanes), dim3(PACK_THREADS), s, planes, k_map, group_bits,
                        tile_bits, g.W, g.npix, g.pack_tiles, g.planes_per_image, t0);
 }
 template void launch_lengths<uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, uint16_t *, uint32_t *,
@@ -1591,22 +1593,22 @@ template void launch_lengths<int32_t>(hipStream_t, const int32_t *, const uint8_
 void launch_bitscan_slice(hipStream_t s, const uint32_t *tile_bits, uint64_t *tile_bitoff, uint64_t *plane_carry,
                           const Geometry &g, uint32_t t0, uint32_t t1) {
     if (t1 <= t0) return;
-    hipLaunchKernelGGL(k_bitscan_slice, dim3(g.nplanes), dim3(1024), 0, s, tile_bits, tile_bitoff, plane_carry,
+    FELICS_LAUNCH(k_bitscan_slice, dim3(g.nplanes), dim3(1024), s, tile_bits, tile_bitoff, plane_carry,
                        g.pack_tiles, t0, t1);
 }
 
 void launch_finish_sizes(hipStream_t s, const uint64_t *plane_carry, uint64_t *plane_base, uint64_t *image_bytes,
                          const Geometry &g) {
-    hipLaunchKernelGGL(k_finish_sizes, dim3(cdiv(g.nimages, 64)), dim3(64), 0, s, plane_carry, plane_base, image_bytes,
+    FELICS_LAUNCH(k_finish_sizes, dim3(cdiv(g.nimages, 64)), dim3(64), s, plane_carry, plane_base, image_bytes,
                        g.nimages, g.planes_per_image);
 }
 
 void launch_place_streams(hipStream_t s, const uint64_t *image_bytes, uint64_t *image_off, const Geometry &g) {
-    hipLaunchKernelGGL(k_place_streams, dim3(1), dim3(64), 0, s, image_bytes, image_off, g.nimages);
+    FELICS_LAUNCH(k_place_streams, dim3(1), dim3(64), s, image_bytes, image_off, g.nimages);
 }
 
 void launch_zero_streams(hipStream_t s, uint32_t *out, const uint64_t *image_off, const Geometry &g) {
-    hipLaunchKernelGGL(k_zero_streams, dim3(256 * 8), dim3(256), 0, s, out, image_off, g.nimages);
+    FELICS_LAUNCH(k_zero_streams, dim3(256 * 8), dim3(256), s, out, image_off, g.nimages);
 }
 
 void launch_zero_edges(hipStream_t s, uint8_t *out, const uint64_t *image_off, uint64_t slot_stride,
@@ -1614,7 +1616,7 @@ void launch_zero_edges(hipStream_t s, uint8_t *out, const uint64_t *image_off, u
                        const Geometry &g, uint32_t t0, uint32_t t1) {
     if (t1 <= t0) return;
     Placement pl{image_off, slot_stride};
-    hipLaunchKernelGGL(k_zero_edges, dim3(cdiv(t1 - t0, 256), g.nplanes), dim3(256), 0, s, out, pl, tile_bitoff, tile_bits,
+    FELICS_LAUNCH(k_zero_edges, dim3(cdiv(t1 - t0, 256), g.nplanes), dim3(256), s, out, pl, tile_bitoff, tile_bits,
                        plane_base, g.pack_tiles, t0, t1, g.planes_per_image);
 }
 
@@ -1625,7 +1627,7 @@ void launch_pack(hipStream_t s, const T *planes, const uint8_t *k_map, const gro
                  uint32_t t1) {
     if (t1 <= t0) return;
     Placement pl{image_off, slot_stride};
-    hipLaunchKernelGGL((k_pack<T>), dim3(t1 - t0, g.nplanes), dim3(PACK_THREADS), 0, s, planes, k_map, group_bits,
+    FELICS_LAUNCH((k_pack<T>), dim3(t1 - t0, g.nplanes), dim3(PACK_THREADS), s, planes, k_map, group_bits,
                        tile_bitoff, tile_bits, plane_base, pl, out, g.W, g.H, g.npix, g.pack_tiles, g.planes_per_image,
                        g.color, g.depth, t0);
 }
@@ -1648,7 +1650,7 @@ void launch_pack_fused(hipStream_t s, const T *planes, const uint8_t *k_map, uin
                        uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t t0, uint32_t t1, uint32_t epoch) {
     if (t1 <= t0) return;
     const PlaneOut po{to.out, to.slot_stride, to.scratch, to.plane_slot, g.planes_per_image};
-    hipLaunchKernelGGL((k_pack_fused<T>), dim3(t1 - t0, g.nplanes), dim3(PACK_THREADS), 0, s, planes, k_map, status,
+    FELICS_LAUNCH((k_pack_fused<T>), dim3(t1 - t0, g.nplanes), dim3(PACK_THREADS), s, planes, k_map, status,
                        tile_bitoff, tile_bits, plane_carry, edge_first, edge_last, error, po, g.W, g.H, g.npix,
                        g.pack_tiles, g.color, g.depth, t0, epoch);
 }
@@ -1662,7 +1664,7 @@ template void launch_pack_fused<int16_t>(hipStream_t, const int16_t *, const uin
 void launch_join_edges(hipStream_t s, const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint32_t *edge_first,
                        const uint32_t *edge_last, const PackTarget &to, const Geometry &g) {
     const PlaneOut po{to.out, to.slot_stride, to.scratch, to.plane_slot, g.planes_per_image};
-    hipLaunchKernelGGL(k_join_edges, dim3(cdiv(g.pack_tiles, 256), g.nplanes), dim3(256), 0, s, tile_bitoff, tile_bits,
+    FELICS_LAUNCH(k_join_edges, dim3(cdiv(g.pack_tiles, 256), g.nplanes), dim3(256), s, tile_bitoff, tile_bits,
                        edge_first, edge_last, po, g.pack_tiles);
 }
 
@@ -1673,7 +1675,7 @@ void launch_concat_planes(hipStream_t s, const uint64_t *plane_base, const uint6
     // the planes behind plane 0 hold at most plane_slot bytes each: enough threads for that many words
     const uint64_t words = (to.plane_slot >> 2) * (g.planes_per_image - 1);
     const uint32_t bx = (uint32_t)std::min<uint64_t>(cdiv(words, 256 * 4), 2048u);
-    hipLaunchKernelGGL(k_concat_planes, dim3(std::max(bx, 1u), g.nimages), dim3(256), 0, s, plane_base, plane_carry, po);
+    FELICS_LAUNCH(k_concat_planes, dim3(std::max(bx, 1u), g.nimages), dim3(256), s, plane_base, plane_carry, po);
 }
 
 }  // namespace felics

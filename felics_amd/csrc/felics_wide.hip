@@ -158,13 +158,13 @@ static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b -
 void launch_rgb16_to_planes(hipStream_t s, const uint16_t *rgb, int32_t *planes, uint32_t npix, uint32_t nimg) {
     const uint64_t total = (uint64_t)npix * nimg;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(cdiv(total, 256), 256u * 32u);
-    hipLaunchKernelGGL(k_rgb16_to_planes, dim3(blocks), dim3(256), 0, s, rgb, planes, npix, nimg);
+    FELICS_LAUNCH(k_rgb16_to_planes, dim3(blocks), dim3(256), s, rgb, planes, npix, nimg);
 }
 
 template <typename T>
 void launch_wide_keys(hipStream_t s, const T *planes, uint32_t *keys, uint32_t *vals, uint32_t *e_of, const Geometry &g) {
     const uint32_t bx = std::min<uint32_t>(cdiv(g.npix, 256), 4096u);
-    hipLaunchKernelGGL((k_wide_keys<T>), dim3(bx, g.nplanes), dim3(256), 0, s, planes, keys, vals, e_of, g.W, g.npix);
+    FELICS_LAUNCH((k_wide_keys<T>), dim3(bx, g.nplanes), dim3(256), s, planes, keys, vals, e_of, g.W, g.npix);
 }
 template void launch_wide_keys<uint16_t>(hipStream_t, const uint16_t *, uint32_t *, uint32_t *, uint32_t *,
                                          const Geometry &);
@@ -188,13 +188,13 @@ hipError_t wide_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *key
 
 void launch_wide_heads(hipStream_t s, const uint32_t *keys, uint32_t n, uint32_t *heads, uint32_t *nheads) {
     const uint32_t blocks = std::min<uint32_t>(cdiv(n, 256), 256u * 16u);
-    hipLaunchKernelGGL(k_wide_heads, dim3(blocks), dim3(256), 0, s, keys, n, heads, nheads);
+    FELICS_LAUNCH(k_wide_heads, dim3(blocks), dim3(256), s, keys, n, heads, nheads);
 }
 
 void launch_wide_chains(hipStream_t s, const uint32_t *keys, const uint32_t *vals, const uint32_t *e_of, uint32_t n,
                         const uint32_t *heads, const uint32_t *nheads, uint8_t *k_map) {
     // persistent: 8 workgroups of 4 waves per CU share the chains
-    hipLaunchKernelGGL(k_wide_chains, dim3(256u * 8u), dim3(256), 0, s, keys, vals, e_of, n, heads, nheads, k_map);
+    FELICS_LAUNCH(k_wide_chains, dim3(256u * 8u), dim3(256), s, keys, vals, e_of, n, heads, nheads, k_map);
 }
 
 }  // namespace felics

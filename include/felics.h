@@ -117,8 +117,9 @@ const char *felics_strerror(int code);
 const char *felics_last_error(const felics_ctx *ctx);
 
 /* ---- measurement hooks (bench.py) ----
- * With profiling on, every kernel launch of the next submission is bracketed by HIP events on the
- * stream it runs on.  A submission launches most kernels once per slice of the image (the stages
+ * With profiling on, every kernel launch of the next submission gets a start / stop HIP event on the
+ * stream it runs on (the kernel's own begin / end for single-kernel stages, event records around the
+ * launches of the few stages that are several small kernels).  A submission launches most kernels once per slice of the image (the stages
  * follow each other slice by slice on several streams); felics_get_stage_ms gives, per stage, the SUM
  * of its launches' durations in milliseconds (launches of different stages overlap, so the stages add
  * up to more than the wall time), felics_get_stage_launches how many launches that was. */

@@ -76,7 +76,8 @@ class Header:  # format.rs:44-49
 
 EXPORTS = [
     "felics_ctx_create", "felics_ctx_destroy", "felics_max_compressed_size", "felics_compress",
-    "felics_compress_batch", "felics_compress_batch_device", "felics_read_header", "felics_write_header",
+    "felics_compress_batch", "felics_compress_batch_device", "felics_submit_batch_device", "felics_wait_batch",
+    "felics_read_header", "felics_write_header",
     "felics_decompress", "felics_strerror", "felics_last_error", "felics_set_profiling",
     "felics_stage_count", "felics_stage_name", "felics_get_stage_ms", "felics_get_stage_launches",
     "felics_lane_count",
@@ -125,6 +126,8 @@ def lib():
                                         C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
     L.felics_compress_batch_device.argtypes = [vp, sz, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, sz,
                                                C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.felics_submit_batch_device.argtypes = [vp, sz, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, sz, C.POINTER(C.c_int)]
+    L.felics_wait_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.felics_read_header.argtypes = [vp, sz, C.POINTER(_CHeader)]
     L.felics_write_header.argtypes = [C.POINTER(_CHeader), vp, sz]
     L.felics_decompress.argtypes = [vp, sz, vp, sz, C.POINTER(_CHeader)]
@@ -226,6 +229,28 @@ class Encoder:
         rc = lib().felics_compress_batch_device(
             self._h, n, d_pixels, w, h, int(color), int(depth), d_out, d_out_cap,
             offs.ctypes.data_as(C.POINTER(C.c_uint64)), lens.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if rc == -8:
+            raise FelicsError(rc, "need %d bytes" % int(lens[0]))
+        if rc != 0:
+            self._raise(rc)
+        return offs, lens
+
+    def submit_batch_device(self, d_pixels, n, w, h, color, depth, d_out, d_out_cap):
+        """Queues a batch and returns a ticket; up to two can be in flight (felics_submit_batch_device)."""
+        ticket = C.c_int(-1)
+        rc = lib().felics_submit_batch_device(self._h, n, d_pixels, w, h, int(color), int(depth), d_out, d_out_cap,
+                                              C.byref(ticket))
+        if rc != 0:
+            self._raise(rc)
+        return ticket.value, n
+
+    def wait_batch(self, submission):
+        """Blocks until the batch of `submission` (from submit_batch_device) is complete: (offsets, lens)."""
+        ticket, n = submission
+        offs = np.zeros(n, dtype=np.uint64)
+        lens = np.zeros(n, dtype=np.uint64)
+        rc = lib().felics_wait_batch(self._h, ticket, offs.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                     lens.ctypes.data_as(C.POINTER(C.c_uint64)))
         if rc == -8:
             raise FelicsError(rc, "need %d bytes" % int(lens[0]))
         if rc != 0:

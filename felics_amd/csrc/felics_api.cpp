@@ -28,8 +28,7 @@ static_assert(ST_COUNT <= FELICS_MAX_STAGES, "felics.h promises at most FELICS_M
 
 constexpr int SLICES = 12;
 constexpr int EV_PAIRS = SLICES + 2;     // launches of one stage per sub-batch that can be timed              // scatter / spine slices per lane: the spine starts after the first quarter
-constexpr int MAX_LANES = 2;            // sub-batches in flight, four HIP streams each (front, spine, k, tail)
-constexpr size_t MIN_LANE_IMAGES = 8;   // below this a sub-batch does not fill the GPU
+constexpr int MAX_LANES = 2;            // submissions in flight (felics_submit_batch_device), each with streams and workspace of its own
 
 struct DevBuf {
     void *p = nullptr;
@@ -56,6 +55,18 @@ struct Lane {
         tile_bits, tile_bitoff, plane_sums, image_bytes, image_off, partial, block_tag, status, edge_first, edge_last, pscratch;
     DevBuf wkeys[2], wvals[2], e_of, heads, sort_temp;  // 16-bit samples: sort records, Rice operands, chain heads
     uint32_t epoch = 0;               // sub-batches this lane has run: block tags are (epoch, slice)
+    // the submission in flight on this lane (felics_submit_batch_device .. felics_wait_batch)
+    bool pending = false;
+    bool finished = false;            // it took the synchronous path: results are in r_off / r_len / r_rc
+    size_t p_n = 0;
+    const void *p_pixels = nullptr;
+    uint32_t p_w = 0, p_h = 0;
+    int p_color = 0, p_depth = 0;
+    uint8_t *p_out = nullptr;
+    size_t p_cap = 0;
+    uint64_t p_slot = 0;
+    std::vector<uint64_t> r_off, r_len;
+    int r_rc = 0;
     // the sub-batch in flight
     Geometry g;
     size_t first_image = 0;
@@ -66,9 +77,8 @@ struct Lane {
 
 struct felics_ctx {
     int device = -1;
-    int max_lanes = 1;          // sub-batches in flight; FELICS_LANES=1..MAX_LANES overrides (tuning)
+    int next_lane = 0;          // lane of the next felics_submit_batch_device
     bool two_pass = false;      // FELICS_TWO_PASS=1, or a look-back of the single-pass pack gave up once: lengths + pack kernels
-    bool single_lane = true;    // the submission in flight uses one lane (set per round)
     bool test_lookback = false; // FELICS_TEST_LOOKBACK_FAIL=1: pretend the first single-pass submission gave up (tests)
     bool poison = false;        // FELICS_POISON=1: overwrite the workspace before every sub-batch (tests)
     bool trace = false;         // FELICS_TRACE=1: synchronise and report after every stage (debugging)
@@ -113,13 +123,14 @@ int wait_event(felics_ctx *ctx, hipEvent_t ev, const char *what) {
     }
 }
 
-int sync_all(felics_ctx *ctx) {
-    for (Lane &l : ctx->lanes) {
-        if (l.front) HIP_TRY(ctx, hipStreamSynchronize(l.front));
-        if (l.stream) HIP_TRY(ctx, hipStreamSynchronize(l.stream));
-        if (l.kstream) HIP_TRY(ctx, hipStreamSynchronize(l.kstream));
-        if (l.tail) HIP_TRY(ctx, hipStreamSynchronize(l.tail));
-    }
+// Waits for everything a lane has queued.  The tail stream is shared by the lanes (the single-pass pack
+// kernels of two submissions must not run side by side), so this also waits for the other lane's packs:
+// used on the synchronous, fallback and error paths only.
+int sync_lane(felics_ctx *ctx, Lane &l) {
+    if (l.front) HIP_TRY(ctx, hipStreamSynchronize(l.front));
+    if (l.stream) HIP_TRY(ctx, hipStreamSynchronize(l.stream));
+    if (l.kstream) HIP_TRY(ctx, hipStreamSynchronize(l.kstream));
+    if (l.tail) HIP_TRY(ctx, hipStreamSynchronize(l.tail));
     return FELICS_OK;
 }
 
@@ -267,9 +278,9 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     if ((epoch & 0x3FFFFu) == 0) HIP_TRY(ctx, hipMemset(l.status.p, 0, l.status.cap));  // look-back tags: 18 epoch bits
     // Fixed slots: code lengths, tile offsets and packing in one kernel per slice (one such kernel at a
     // time: the tiles of two of them waiting for each other's queued predecessors could hold all workgroup
-    // slots, so sub-batches running side by side use the two-pass kernels).  It puts planes 1, 2 of an RGB
-    // image into scratch slots of their own and moves them behind plane 0 at the end.
-    const bool fused = slot_stride != 0 && !ctx->two_pass && ctx->single_lane;
+    // slots, so the lanes share the tail stream).  It puts planes 1, 2 of an RGB image into scratch slots of
+    // their own and moves them behind plane 0 at the end.
+    const bool fused = slot_stride != 0 && !ctx->two_pass;
     // Two-pass kernels: gray frames pack slice by slice; RGB packs after the last slice (the offset of planes
     // 1 and 2 in their stream needs the size of the planes before them).
     const bool pack_by_slice = slot_stride != 0 && g.planes_per_image == 1;
@@ -506,19 +517,18 @@ int pack_exact(felics_ctx *ctx, Lane &l, uint8_t *d_out) {
     return FELICS_OK;
 }
 
-void collect_timing(felics_ctx *ctx) {
+void collect_timing(felics_ctx *ctx, Lane &l) {
     if (!ctx->profiling) return;
     for (int i = 0; i < ST_COUNT; i++) {
         ctx->stage_ms[i] = 0.f;  // sum of the launches' durations (launches overlap: the sum can exceed wall time)
         ctx->stage_launches[i] = 0;
-        for (Lane &l : ctx->lanes)
-            for (int k = 0; k < l.ev_used[i]; k++) {
-                float ms = 0.f;
-                if (hipEventElapsedTime(&ms, l.ev[i][k][0], l.ev[i][k][1]) == hipSuccess) {
-                    ctx->stage_ms[i] += ms;
-                    ctx->stage_launches[i]++;
-                }
+        for (int k = 0; k < l.ev_used[i]; k++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, l.ev[i][k][0], l.ev[i][k][1]) == hipSuccess) {
+                ctx->stage_ms[i] += ms;
+                ctx->stage_launches[i]++;
             }
+        }
     }
 }
 
@@ -533,17 +543,72 @@ size_t max_images_per_pass(uint64_t npix, uint32_t planes, int depth) {
     return (size_t)std::max<uint64_t>(1, 0xE0000000ull / (per_image + 64ull * planes * NCTX));
 }
 
-// Encode `n` same-shape frames resident in device memory into d_out (device).
+// Queues one sub-batch (cnt frames starting at frame `first` of d_pixels) on a lane: geometry, colour
+// transform, and everything run_lane / run_wide enqueue.  Returns without waiting.
+int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const void *d_pixels, uint32_t w, uint32_t h,
+                     int color, int depth, uint8_t *lane_out, uint64_t slot) {
+    const uint32_t planes = color == FELICS_COLOR_RGB ? 3 : 1;
+    const uint64_t npix = (uint64_t)w * h;
+    const bool wide = depth == FELICS_DEPTH_16;
+    const size_t frame_bytes = (size_t)npix * planes * (wide ? 2 : 1);
+    int rc;
+    Geometry &g = l.g;
+    g.W = w;
+    g.H = h;
+    g.npix = (uint32_t)npix;
+    g.nimages = (uint32_t)cnt;
+    g.planes_per_image = planes;
+    g.nplanes = (uint32_t)(cnt * planes);
+    g.sort_tiles = (uint32_t)((npix + SORT_TILE - 1) / SORT_TILE);
+    g.pack_tiles = (uint32_t)((npix + PACK_TILE - 1) / PACK_TILE);
+    g.color = (uint32_t)color;
+    g.depth = (uint32_t)depth;
+    l.first_image = first;
+    const uint8_t *src = (const uint8_t *)d_pixels + first * frame_bytes;
+    l.d_planes = src;
+    if (planes == 3) {
+        if ((rc = reserve(ctx, l.planes, (size_t)g.nplanes * npix * (wide ? 4 : 2) + STAGE_PAD)) != 0) return rc;
+        hipStream_t fs = wide || getenv("FELICS_SERIAL") ? l.stream : l.front;
+        StageTimer t(ctx, l, ST_PLANES, fs, true);
+        if (wide)
+            launch_rgb16_to_planes(fs, (const uint16_t *)src, (int32_t *)l.planes.p, g.npix, g.nimages);
+        else
+            launch_rgb8_to_planes(fs, src, (int16_t *)l.planes.p, g.npix, g.nimages);
+        l.d_planes = l.planes.p;
+    }
+    if (wide) return planes == 3 ? run_wide<int32_t>(ctx, l, lane_out, slot) : run_wide<uint16_t>(ctx, l, lane_out, slot);
+    return planes == 3 ? run_lane<int16_t, uint16_t>(ctx, l, lane_out, slot) : run_lane<uint8_t, uint8_t>(ctx, l, lane_out, slot);
+}
+
+// What the sizes that came back say about a sub-batch packed into fixed slots.
+struct SlotOutcome {
+    bool lookback_failed = false;  // a tile of the single-pass pack gave up waiting for the tiles before it
+    bool overflow = false;         // a stream outgrew its slot, or an RGB plane its scratch slot
+};
+
+SlotOutcome read_sizes(felics_ctx *ctx, Lane &l, bool wide, uint64_t slot, uint64_t *offsets, uint64_t *lens) {
+    SlotOutcome o;
+    if (!wide && ((l.h_sizes[l.g.nimages] & 1u) != 0 || (ctx->test_lookback && !ctx->two_pass))) o.lookback_failed = true;
+    if (!wide && (l.h_sizes[l.g.nimages] & 2u) != 0) o.overflow = true;
+    for (size_t i = 0; i < l.g.nimages; i++) {
+        lens[l.first_image + i] = l.h_sizes[i];
+        offsets[l.first_image + i] = (uint64_t)(l.first_image + i) * slot;
+        if (slot != 0 && l.h_sizes[i] > slot) o.overflow = true;
+    }
+    return o;
+}
+
+// Encode `n` same-shape frames resident in device memory into d_out (device), on one lane, and wait.
 // If d_out is NULL the context's own output buffer is used (and grown).
-int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, uint32_t h, int color, int depth,
-                  uint8_t *d_out, size_t d_out_cap, uint64_t *offsets, uint64_t *lens, uint8_t **used_out) {
+int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint32_t w, uint32_t h, int color, int depth,
+                  uint8_t *d_out, size_t d_out_cap, uint64_t *offsets, uint64_t *lens, uint8_t **used_out,
+                  bool start_exact = false) {
     const uint32_t planes = color == FELICS_COLOR_RGB ? 3 : 1;
     const uint64_t npix = (uint64_t)w * h;
     const bool wide = depth == FELICS_DEPTH_16;
     if (npix * planes >= 0xE0000000ull) return FELICS_E_UNSUPPORTED;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    for (Lane &l : ctx->lanes)
-        for (int i = 0; i < ST_COUNT; i++) l.ev_used[i] = 0;
+    for (int i = 0; i < ST_COUNT; i++) l.ev_used[i] = 0;
     const bool own_out = d_out == nullptr;
 
     if (npix == 0) {
@@ -589,123 +654,74 @@ int encode_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, u
         slot = (d_out_cap / n) & ~15ull;
         if (slot < 64 || slot < frame_bytes / 4) slot = 0;
     }
+    if (start_exact) slot = 0;
 
     for (int attempt = 0; attempt < 3; attempt++) {
         size_t done = 0;
-        bool lookback_failed = false;
-        uint64_t out_base = 0;  // exact placement: where the next round's streams start
-        bool overflow = false;
-        // Rounds of up to max_lanes sub-batches (one round unless the batch is huge).
-        while (done < n && !overflow && !lookback_failed) {
-            const size_t left = n - done;
-            const size_t nl = wide ? 1 : std::min<size_t>((size_t)ctx->max_lanes, std::max<size_t>(1, left / MIN_LANE_IMAGES));
-            // Later lanes get fewer images (weights nl, nl-1, .., 1): every lane pays the same spine
-            // latency, so the lane that starts last should have the least work left after its spine.
-            const size_t wsum = nl * (nl + 1) / 2;
-            ctx->single_lane = nl == 1;
-            size_t first = done;
-            int used = 0;
-            for (size_t li = 0; li < nl && first < n; li++) {
-                Lane &l = ctx->lanes[li];
-                size_t share = li + 1 == nl ? n - first : (left * (nl - li) + wsum - 1) / wsum;
-                const size_t cnt = std::min(std::min(per_pass, std::max<size_t>(1, share)), n - first);
-                Geometry &g = l.g;
-                g.W = w;
-                g.H = h;
-                g.npix = (uint32_t)npix;
-                g.nimages = (uint32_t)cnt;
-                g.planes_per_image = planes;
-                g.nplanes = (uint32_t)(cnt * planes);
-                g.sort_tiles = (uint32_t)((npix + SORT_TILE - 1) / SORT_TILE);
-                g.pack_tiles = (uint32_t)((npix + PACK_TILE - 1) / PACK_TILE);
-                g.color = (uint32_t)color;
-                g.depth = (uint32_t)depth;
-                l.first_image = first;
-                const uint8_t *src = (const uint8_t *)d_pixels + first * frame_bytes;
-                l.d_planes = src;
-                if (planes == 3) {
-                    if ((rc = reserve(ctx, l.planes, (size_t)g.nplanes * npix * (wide ? 4 : 2) + STAGE_PAD)) != 0) return rc;
-                    hipStream_t fs = wide || getenv("FELICS_SERIAL") ? l.stream : l.front;
-                    StageTimer t(ctx, l, ST_PLANES, fs, true);
-                    if (wide)
-                        launch_rgb16_to_planes(fs, (const uint16_t *)src, (int32_t *)l.planes.p, g.npix, g.nimages);
-                    else
-                        launch_rgb8_to_planes(fs, src, (int16_t *)l.planes.p, g.npix, g.nimages);
-                    l.d_planes = l.planes.p;
-                }
-                uint8_t *lane_out = d_out + first * slot;
-                if (wide)
-                    rc = planes == 3 ? run_wide<int32_t>(ctx, l, lane_out, slot) : run_wide<uint16_t>(ctx, l, lane_out, slot);
-                else
-                    rc = planes == 3 ? run_lane<int16_t, uint16_t>(ctx, l, lane_out, slot)
-                                     : run_lane<uint8_t, uint8_t>(ctx, l, lane_out, slot);
-                if (rc) {
-                    (void)sync_all(ctx);
-                    return rc;
-                }
-                first += cnt;
-                used++;
+        uint64_t out_base = 0;  // exact placement: where the next pass's streams start
+        SlotOutcome outcome;
+        // passes of up to per_pass frames (one pass unless the batch is huge)
+        while (done < n && !outcome.overflow && !outcome.lookback_failed) {
+            const size_t cnt = std::min(per_pass, n - done);
+            const size_t first = done + cnt;
+            if ((rc = launch_sub_batch(ctx, l, done, cnt, d_pixels, w, h, color, depth, d_out + done * slot, slot)) != 0) {
+                (void)sync_lane(ctx, l);
+                return rc;
             }
-            for (int li = 0; li < used; li++) {
-                Lane &l = ctx->lanes[li];
-                if ((rc = wait_event(ctx, l.sized, "stream sizes")) != 0) return rc;
-                if (!wide && ((l.h_sizes[l.g.nimages] & 1u) != 0 || (ctx->test_lookback && !ctx->two_pass))) lookback_failed = true;
-                if (!wide && (l.h_sizes[l.g.nimages] & 2u) != 0) overflow = true;  // an RGB plane outgrew its scratch slot
-                for (size_t i = 0; i < l.g.nimages; i++) {
-                    lens[l.first_image + i] = l.h_sizes[i];
-                    offsets[l.first_image + i] = (uint64_t)(l.first_image + i) * slot;
-                    if (slot != 0 && l.h_sizes[i] > slot) overflow = true;
-                }
-            }
+            if ((rc = wait_event(ctx, l.sized, "stream sizes")) != 0) return rc;
+            outcome = read_sizes(ctx, l, wide, slot, offsets, lens);
             if (slot == 0) {
-                // exact placement of this round: back to back, 16-byte aligned, in image order
+                // exact placement of this pass: back to back, 16-byte aligned, in image order
                 uint64_t need = out_base;
                 for (size_t i = done; i < first; i++) {
                     offsets[i] = need;
                     need += (lens[i] + 15) & ~15ull;
                 }
                 if (own_out) {
-                    if (done != 0) return FELICS_E_UNSUPPORTED;  // the host entry points submit one round at a time
+                    if (done != 0) return FELICS_E_UNSUPPORTED;  // the host entry points submit one pass at a time
                     if ((rc = reserve(ctx, ctx->out, (size_t)need)) != 0) return rc;  // waits for the device
                     d_out = (uint8_t *)ctx->out.p;
                     d_out_cap = ctx->out.cap;
                 }
                 if (need > d_out_cap) {
-                    (void)sync_all(ctx);
-                    lens[0] = need;  // capacity needed so far (a lower bound if more rounds would follow)
+                    (void)sync_lane(ctx, l);
+                    lens[0] = need;  // capacity needed so far (a lower bound if more passes would follow)
                     return FELICS_E_BUFFER_TOO_SMALL;
                 }
-                for (int li = 0; li < used; li++) {
-                    Lane &l = ctx->lanes[li];
-                    launch_place_streams(l.tail, (const uint64_t *)l.image_bytes.p, (uint64_t *)l.image_off.p, l.g);
-                    uint8_t *lane_out = d_out + offsets[l.first_image];
-                    if (wide)
-                        rc = planes == 3 ? pack_exact<int32_t>(ctx, l, lane_out) : pack_exact<uint16_t>(ctx, l, lane_out);
-                    else
-                        rc = planes == 3 ? pack_exact<int16_t>(ctx, l, lane_out) : pack_exact<uint8_t>(ctx, l, lane_out);
-                    if (rc) {
-                        (void)sync_all(ctx);
-                        return rc;
-                    }
+                launch_place_streams(l.tail, (const uint64_t *)l.image_bytes.p, (uint64_t *)l.image_off.p, l.g);
+                uint8_t *lane_out = d_out + offsets[l.first_image];
+                if (wide)
+                    rc = planes == 3 ? pack_exact<int32_t>(ctx, l, lane_out) : pack_exact<uint16_t>(ctx, l, lane_out);
+                else
+                    rc = planes == 3 ? pack_exact<int16_t>(ctx, l, lane_out) : pack_exact<uint8_t>(ctx, l, lane_out);
+                if (rc) {
+                    (void)sync_lane(ctx, l);
+                    return rc;
                 }
                 out_base = need;
             }
-            if ((rc = sync_all(ctx)) != 0) return rc;
+            if ((rc = sync_lane(ctx, l)) != 0) return rc;
             done = first;
         }
-        if (lookback_failed) {
+        if (outcome.lookback_failed) {
             // A tile of the single-pass pack gave up waiting for the tiles before it (another context's
             // kernels holding the GPU, most likely): this context packs in two passes from now on.
-            if ((rc = sync_all(ctx)) != 0) return rc;
+            if ((rc = sync_lane(ctx, l)) != 0) return rc;
             ctx->two_pass = true;
             continue;
         }
-        if (!overflow) break;
+        if (!outcome.overflow) break;
         slot = 0;  // a stream outgrew its slot: do the batch again with exact placement
     }
-    collect_timing(ctx);
+    collect_timing(ctx, l);
     if (used_out) *used_out = d_out;
     return FELICS_OK;
+}
+
+bool any_pending(const felics_ctx *ctx) {
+    for (const Lane &l : ctx->lanes)
+        if (l.pending) return true;
+    return false;
 }
 
 }  // namespace
@@ -733,10 +749,6 @@ int felics_ctx_create(int device, felics_ctx **out) {
     ctx->test_lookback = getenv("FELICS_TEST_LOOKBACK_FAIL") != nullptr;
     ctx->trace = getenv("FELICS_TRACE") != nullptr;
     if (const char *e = getenv("FELICS_TIMEOUT_S")) ctx->timeout_s = std::max(1, atoi(e));
-    if (const char *e = getenv("FELICS_LANES")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= MAX_LANES) ctx->max_lanes = v;
-    }
     bool ok = hipSetDevice(device) == hipSuccess;
     // The scatter slices and the spine are the critical path: their streams get the highest priority, so
     // the kernels that trail behind (k, lengths, pack) do not delay them when the GPU is full.
@@ -746,7 +758,11 @@ int felics_ctx_create(int device, felics_ctx **out) {
         ok = ok && hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio_high) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&l.front, hipStreamNonBlocking, prio_high) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&l.kstream, hipStreamNonBlocking, prio_low) == hipSuccess;
-        ok = ok && hipStreamCreateWithPriority(&l.tail, hipStreamNonBlocking, prio_low) == hipSuccess;
+        // one tail stream for all lanes: the single-pass pack kernels of two submissions run one after the other
+        if (&l == &ctx->lanes[0])
+            ok = ok && hipStreamCreateWithPriority(&l.tail, hipStreamNonBlocking, prio_low) == hipSuccess;
+        else
+            l.tail = ctx->lanes[0].tail;
         for (int q = 0; q < SLICES && ok; q++) {
             ok = hipEventCreateWithFlags(&l.slice_done[q], hipEventDisableTiming) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&l.spine_done[q], hipEventDisableTiming) == hipSuccess;
@@ -790,7 +806,7 @@ void felics_ctx_destroy(felics_ctx *ctx) {
             if (l.assign_done[q]) (void)hipEventDestroy(l.assign_done[q]);
         }
         if (l.front) (void)hipStreamDestroy(l.front);
-        if (l.tail) (void)hipStreamDestroy(l.tail);
+        if (l.tail && &l == &ctx->lanes[0]) (void)hipStreamDestroy(l.tail);
         if (l.kstream) (void)hipStreamDestroy(l.kstream);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
@@ -813,7 +829,79 @@ int felics_compress_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels
     int rc = check_args(w, h, color, depth);
     if (rc) return rc;
     if (n == 0) return FELICS_OK;
-    return encode_device(ctx, n, d_pixels, w, h, color, depth, (uint8_t *)d_out, d_out_cap, offsets, lens, nullptr);
+    if (any_pending(ctx)) return FELICS_E_INVALID_ARGUMENT;  // felics_wait_batch first
+    return encode_device(ctx, ctx->lanes[0], n, d_pixels, w, h, color, depth, (uint8_t *)d_out, d_out_cap, offsets, lens,
+                         nullptr);
+}
+
+int felics_submit_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, uint32_t h, int color,
+                               int depth, void *d_out, size_t d_out_cap, int *ticket) {
+    if (!ctx || !ticket || !d_out || n == 0 || (!d_pixels && (uint64_t)w * h)) return FELICS_E_INVALID_ARGUMENT;
+    int rc = check_args(w, h, color, depth);
+    if (rc) return rc;
+    const int L = ctx->next_lane;
+    Lane &l = ctx->lanes[L];
+    if (l.pending) return FELICS_E_INVALID_ARGUMENT;  // MAX_LANES submissions are in flight: wait for the oldest
+    l.p_n = n;
+    l.p_pixels = d_pixels;
+    l.p_w = w;
+    l.p_h = h;
+    l.p_color = color;
+    l.p_depth = depth;
+    l.p_out = (uint8_t *)d_out;
+    l.p_cap = d_out_cap;
+    l.finished = false;
+    const uint32_t planes = color == FELICS_COLOR_RGB ? 3 : 1;
+    const uint64_t npix = (uint64_t)w * h;
+    const size_t frame_bytes = (size_t)npix * planes * (depth == FELICS_DEPTH_16 ? 2 : 1);
+    uint64_t slot = (d_out_cap / n) & ~15ull;
+    if (slot < 64 || slot < frame_bytes / 4) slot = 0;
+    if (npix == 0 || npix * planes >= 0xE0000000ull || n > max_images_per_pass(npix, planes, depth) || slot == 0) {
+        // not the plain case (fixed slots, one pass): do it now, hand the result over at the wait
+        l.r_off.assign(n, 0);
+        l.r_len.assign(n, 0);
+        l.r_rc = encode_device(ctx, l, n, d_pixels, w, h, color, depth, l.p_out, d_out_cap, l.r_off.data(), l.r_len.data(),
+                               nullptr);
+        l.finished = true;
+    } else {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        for (int i = 0; i < ST_COUNT; i++) l.ev_used[i] = 0;
+        l.p_slot = slot;
+        if ((rc = launch_sub_batch(ctx, l, 0, n, d_pixels, w, h, color, depth, l.p_out, slot)) != 0) {
+            (void)sync_lane(ctx, l);
+            return rc;
+        }
+    }
+    l.pending = true;
+    *ticket = L;
+    ctx->next_lane = (L + 1) % MAX_LANES;
+    return FELICS_OK;
+}
+
+int felics_wait_batch(felics_ctx *ctx, int ticket, uint64_t *offsets, uint64_t *lens) {
+    if (!ctx || ticket < 0 || ticket >= MAX_LANES || !offsets || !lens) return FELICS_E_INVALID_ARGUMENT;
+    Lane &l = ctx->lanes[ticket];
+    if (!l.pending) return FELICS_E_INVALID_ARGUMENT;
+    l.pending = false;
+    if (l.finished) {
+        for (size_t i = 0; i < l.p_n; i++) {
+            offsets[i] = l.r_off[i];
+            lens[i] = l.r_len[i];
+        }
+        return l.r_rc;
+    }
+    int rc;
+    if ((rc = wait_event(ctx, l.sized, "stream sizes")) != 0) return rc;
+    const SlotOutcome o = read_sizes(ctx, l, l.p_depth == FELICS_DEPTH_16, l.p_slot, offsets, lens);
+    if (!o.lookback_failed && !o.overflow) {
+        collect_timing(ctx, l);
+        return FELICS_OK;
+    }
+    // the rare cases: pack again on this lane, synchronously (two-pass kernels / exact placement)
+    if ((rc = sync_lane(ctx, l)) != 0) return rc;
+    if (o.lookback_failed) ctx->two_pass = true;
+    return encode_device(ctx, l, l.p_n, l.p_pixels, l.p_w, l.p_h, l.p_color, l.p_depth, l.p_out, l.p_cap, offsets, lens,
+                         nullptr, o.overflow && !o.lookback_failed);
 }
 
 int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, uint32_t w, uint32_t h, int color,
@@ -822,6 +910,7 @@ int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, 
     int rc = check_args(w, h, color, depth);
     if (rc) return rc;
     if (n == 0) return FELICS_OK;
+    if (any_pending(ctx)) return FELICS_E_INVALID_ARGUMENT;  // felics_wait_batch first
     const uint32_t planes = color == FELICS_COLOR_RGB ? 3 : 1;
     const size_t frame_bytes = (size_t)w * h * planes * (depth == FELICS_DEPTH_16 ? 2 : 1);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -840,7 +929,7 @@ int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, 
         offs.assign(cnt, 0);
         sizes.assign(cnt, 0);
         uint8_t *d_out = nullptr;
-        rc = encode_device(ctx, cnt, ctx->in.p, w, h, color, depth, nullptr, 0, offs.data(), sizes.data(), &d_out);
+        rc = encode_device(ctx, ctx->lanes[0], cnt, ctx->in.p, w, h, color, depth, nullptr, 0, offs.data(), sizes.data(), &d_out);
         if (rc) return rc;
         for (size_t i = 0; i < cnt; i++) {
             lens[first + i] = (size_t)sizes[i];

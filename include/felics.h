@@ -100,6 +100,19 @@ int felics_compress_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels
                                  uint32_t h, int color, int depth, void *d_out,
                                  size_t d_out_cap, uint64_t *offsets, uint64_t *lens);
 
+/* The same submission in two halves, for callers that encode batch after batch: felics_submit_batch_device
+ * queues the work and returns, felics_wait_batch(ticket) blocks until that batch is complete and fills
+ * offsets / lens.  Up to felics_lane_count() (2) submissions can be in flight, each with its own d_out;
+ * tickets must be waited for in the order they were handed out.  While the GPU is finishing one batch (its
+ * last pack slices) it already classifies, scatters and replays the estimator of the next one, which hides
+ * the latency-bound head and tail of a batch.  The synchronous entry points refuse to run
+ * (FELICS_E_INVALID_ARGUMENT) while a ticket is outstanding.  The reference has no counterpart (it is one
+ * blocking call per image); a Rust wrapper would expose this as a two-deep pipeline over `compress`. */
+int felics_submit_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w,
+                               uint32_t h, int color, int depth, void *d_out, size_t d_out_cap,
+                               int *ticket);
+int felics_wait_batch(felics_ctx *ctx, int ticket, uint64_t *offsets, uint64_t *lens);
+
 /* Replaces `read_header` (format.rs:63-84). */
 int felics_read_header(const uint8_t *in, size_t len, felics_header *hdr);
 /* Replaces `write_header` (format.rs:51-61): writes FELICS_HEADER_BYTES bytes. */
@@ -129,7 +142,7 @@ int felics_stage_count(void);
 const char *felics_stage_name(int stage);
 int felics_get_stage_ms(const felics_ctx *ctx, float *ms, int cap);
 int felics_get_stage_launches(const felics_ctx *ctx, int *launches, int cap);
-/* Upper bound of the sub-batches one submission is split into (each with its own streams). */
+/* Submissions that can be in flight at a time (felics_submit_batch_device). */
 int felics_lane_count(void);
 
 #ifdef __cplusplus

@@ -216,14 +216,13 @@ def test_sixteen_bit_4k(enc, oracle):
 
 def test_pack_variants(oracle):
     """The single-pass pack is the default for gray frames; FELICS_TWO_PASS selects the lengths + pack kernels,
-    a look-back that gives up makes the context fall back to them, and sub-batches that run side by side
-    (FELICS_LANES=2) use them as well.  All must produce the oracle's bytes."""
+    and a look-back that gives up makes the context fall back to them.  All must produce the oracle's bytes."""
     import felics_amd
     from felics_amd import synth
 
     frames = [synth.gray8(1920, 1080, f, "S1") for f in range(16)] + [synth.gray8(1920, 1080, 3, "S2")]
     want = [oracle.compress(f) for f in frames]
-    for env in ({}, {"FELICS_TWO_PASS": "1"}, {"FELICS_TEST_LOOKBACK_FAIL": "1"}, {"FELICS_LANES": "2"}):
+    for env in ({}, {"FELICS_TWO_PASS": "1"}, {"FELICS_TEST_LOOKBACK_FAIL": "1"}):
         os.environ.update(env)
         os.environ["FELICS_POISON"] = "1"
         try:
@@ -295,6 +294,53 @@ def test_several_passes(oracle):
                 assert host[int(offs[i]): int(offs[i] + lens[i])].tobytes() == oracle.compress(f)
     finally:
         del os.environ["FELICS_TEST_PASS_IMAGES"]
+
+
+def test_two_submissions_in_flight(enc, oracle):
+    """felics_submit_batch_device / felics_wait_batch: batch i + 1 is queued before batch i is waited for (gray,
+    RGB with a slot overflow in one batch, 16-bit; different shapes back to back), every stream checked."""
+    import felics_amd
+    import torch
+    from felics_amd import synth
+
+    rng = np.random.default_rng(9)
+    batches = []
+    for b in range(6):
+        if b % 3 == 0:
+            frames, color, depth = [synth.gray8(1280, 720, 10 * b + f, "S1") for f in range(6)], 0, 0
+        elif b % 3 == 1:
+            frames, color, depth = [synth.rgb8(640, 360, 10 * b + f) for f in range(4)], 1, 0
+            if b == 4:  # noise does not fit the slots below: exact placement on the wait
+                frames[2] = rng.integers(0, 256, size=frames[2].shape, dtype=np.uint8)
+        else:
+            frames, color, depth = [synth.gray16(800, 600, 10 * b + f) for f in range(3)], 0, 1
+        batches.append((frames, color, depth))
+    d_in = [torch.from_numpy(np.stack(fr).view(np.uint8)).cuda() for fr, _, _ in batches]
+    caps = [int(sum(f.nbytes for f in fr) * 1.1) + 4096 for fr, _, _ in batches]
+    d_out = [torch.zeros(c, dtype=torch.uint8, device="cuda") for c in caps]
+    torch.cuda.synchronize()
+
+    def submit(b):
+        fr, color, depth = batches[b]
+        h, w = fr[0].shape[:2]
+        return enc.submit_batch_device(d_in[b].data_ptr(), len(fr), w, h, color, depth, d_out[b].data_ptr(), caps[b])
+
+    def check(b, offs, lens):
+        host = d_out[b].cpu().numpy()
+        for i, f in enumerate(batches[b][0]):
+            assert host[int(offs[i]): int(offs[i] + lens[i])].tobytes() == oracle.compress(f), (b, i)
+
+    pending = submit(0)
+    for b in range(1, len(batches)):
+        nxt = submit(b)
+        with pytest.raises(felics_amd.FelicsError):  # the synchronous entry points wait their turn
+            enc.compress(batches[0][0][0])
+        check(b - 1, *enc.wait_batch(pending))
+        pending = nxt
+    check(len(batches) - 1, *enc.wait_batch(pending))
+    with pytest.raises(felics_amd.FelicsError):
+        enc.wait_batch(pending)  # nothing is outstanding any more
+    assert enc.compress(batches[0][0][0]) == oracle.compress(batches[0][0][0])
 
 
 def test_errors(enc):

@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--check-frames", type=int, default=2, help="frames byte-compared with the oracle before timing")
     ap.add_argument("--synchronous", action="store_true", help="time the blocking entry point (one batch at a time)")
+    ap.add_argument("--no-blocking-extra", action="store_true",
+                    help="skip the three extra blocking-call steps after the timed region (rocprofv3 runs: keeps the kernel averages those of the timed steps)")
     return ap.parse_args()
 
 
@@ -199,7 +201,7 @@ def main():
             raise SystemExit("rank %d: output changed between steps" % rank)
     # for the record: a few steps through the blocking entry point (one batch at a time)
     sync_ms = None
-    if not args.synchronous and rank == 0:
+    if not args.synchronous and not args.no_blocking_extra and rank == 0:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(3):

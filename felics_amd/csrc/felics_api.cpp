@@ -27,7 +27,7 @@ const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "sp
 static_assert(ST_COUNT <= FELICS_MAX_STAGES, "felics.h promises at most FELICS_MAX_STAGES stages");
 
 constexpr int SLICES = 12;
-constexpr int EV_PAIRS = SLICES + 2;     // launches of one stage per sub-batch that can be timed              // scatter / spine slices per lane: the spine starts after the first quarter
+constexpr int EV_PAIRS = SLICES + 2;     // launches of one stage per sub-batch that can be timed
 constexpr int MAX_LANES = 2;            // submissions in flight (felics_submit_batch_device), each with streams and workspace of its own
 
 struct DevBuf {
@@ -35,9 +35,9 @@ struct DevBuf {
     size_t cap = 0;
 };
 
-// One pipeline lane: a HIP stream, its stage events and its own workspace in HBM.  The replay of the
-// Rice-parameter estimator (k_spine) is a handful of long sequential waves; with several lanes the
-// data-parallel kernels of one sub-batch run underneath the spine of another.
+// One pipeline lane: HIP streams, stage events and a workspace in HBM of its own.  A submission (or one pass of
+// a huge one) runs on one lane; felics_submit_batch_device hands the lanes out in turn, so that the GPU starts
+// on the next batch while it finishes the last pack slices of this one.
 struct Lane {
     hipStream_t stream = nullptr;      // spine slices
     hipStream_t front = nullptr;       // planes, hist, offsets, scatter slices

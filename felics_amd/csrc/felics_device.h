@@ -104,6 +104,27 @@ __device__ __forceinline__ void load4(const int16_t *__restrict__ p, int (&v)[4]
 // Interior pixels of one image row (x > 0, y > 0 for all), four per lane: left and above from two wide loads.
 // A wave covers 256 consecutive pixels (lane l: first + 4l ..), so the sample left of a lane's first pixel
 // is the last sample of the lane before it (one DPP wave shift); lane 0 fetches its own.
+// Split in two so that a caller can have the next trip's loads in flight while it works on this one.
+struct Interior4 {
+    int cur[4], up[4], left_lane0;
+};
+
+template <typename T>
+__device__ __forceinline__ void load_interior4(const T *__restrict__ pl, uint32_t first, uint32_t W, Interior4 &v) {
+    const uint32_t i = first + 4 * lane_id();
+    load4(pl + i, v.cur);
+    load4(pl + i - W, v.up);
+    v.left_lane0 = (int)pl[first - 1];  // same address in every lane: one scalar-like access
+}
+
+__device__ __forceinline__ void classify_loaded4(const Interior4 &v, PixelClass (&pc)[4]) {
+    int left0 = __builtin_amdgcn_update_dpp(0, v.cur[3], 0x138, 0xF, 0xF, false);  // wave_shr:1
+    if (lane_id() == 0) left0 = v.left_lane0;
+    pc[0] = classify_values(v.cur[0], left0, v.up[0]);
+#pragma unroll
+    for (int j = 1; j < 4; j++) pc[j] = classify_values(v.cur[j], v.cur[j - 1], v.up[j]);
+}
+
 template <typename T>
 __device__ __forceinline__ void classify_interior4(const T *__restrict__ pl, uint32_t first, uint32_t W,
                                                    PixelClass (&pc)[4]) {

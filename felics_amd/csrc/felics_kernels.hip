@@ -105,14 +105,30 @@ __global__ __launch_bounds__(256) void k_hist(const T *__restrict__ planes, uint
         // row with x > 0, y > 0 -- nearly all of them -- takes the neighbour rule's interior case
         // without any per-pixel case analysis.
         uint32_t y0 = begin / W, x0 = begin - y0 * W;
+        auto is_interior = [&](uint32_t r, uint32_t x, uint32_t y) { return y > 0 && x > 0 && x + 256 <= W && r + 256 <= end; };
+        Interior4 nxt;
+        bool have_nxt = false;  // the next trip's loads were issued during the trip before
+        if (begin < end && is_interior(begin, x0, y0)) {
+            load_interior4(pl, begin, W, nxt);
+            have_nxt = true;
+        }
         for (uint32_t r0 = begin; r0 < end; r0 += 256) {
             PixelClass pc[4];
             bool ev[4];
-            const bool interior = y0 > 0 && x0 > 0 && x0 + 256 <= W && r0 + 256 <= end;
+            const bool interior = have_nxt;
+            const Interior4 now = nxt;
+            // where the next trip starts
+            uint32_t x1 = x0 + 256, y1 = y0;
+            while (x1 >= W) {
+                x1 -= W;
+                y1++;
+            }
+            have_nxt = r0 + 256 < end && is_interior(r0 + 256, x1, y1);
+            if (have_nxt) load_interior4(pl, r0 + 256, W, nxt);  // in flight while this trip is counted
             if (interior) {
                 // lane l takes pixels r0 + 4l .. + 3: two wide loads instead of twelve byte loads (counting
                 // does not care which lane sees which pixel)
-                classify_interior4(pl, r0, W, pc);
+                classify_loaded4(now, pc);
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++) ev[u] = pc[u].cls != CLS_IN;
             } else {
@@ -134,11 +150,8 @@ __global__ __launch_bounds__(256) void k_hist(const T *__restrict__ planes, uint
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++)
                 if (ev[u]) atomicAdd(&hist[wave][pc[u].ctx], 1u);
-            x0 += 256;
-            while (x0 >= W) {
-                x0 -= W;
-                y0++;
-            }
+            x0 = x1;
+            y0 = y1;
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t *dst = counts + ((uint64_t)plane * ntiles + tile) * NCTX;

@@ -142,6 +142,25 @@ def test_4k_frame(enc, oracle):
     _check(enc, oracle, synth.rgb8(3840, 2160, 0), "4K rgb")
 
 
+def test_baseline_batch_round_trip(enc, oracle):
+    """BASELINE config 3 at full size (64 synthetic 4K frames in one submission): every stream decodes back to
+    its frame (size-independent property), four of them are also byte-compared with the oracle, and the sizes add
+    up to what the oracle's say for those four."""
+    import felics_amd
+    from felics_amd import synth
+
+    frames = [synth.gray8(3840, 2160, f, "S1") for f in range(64)]
+    streams = enc.compress_batch(frames)
+    assert len(streams) == 64
+    for i in (0, 21, 42, 63):
+        assert streams[i] == oracle.compress(frames[i]), i
+    for i, (f, st) in enumerate(zip(frames, streams)):
+        hdr = felics_amd.read_header(io.BytesIO(st[:14]))
+        assert (hdr.width, hdr.height) == (3840, 2160)
+        back = felics_amd.decompress_image(io.BytesIO(st))
+        assert back.dtype == np.uint8 and (back == f).all(), i
+
+
 def test_device_resident_batch(enc, oracle):
     """felics_compress_batch_device with torch holding the HBM buffers (plumbing only)."""
     import torch

@@ -26,7 +26,7 @@ const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "sp
                                      "wide_keys", "wide_sort", "wide_chains"};
 static_assert(ST_COUNT <= FELICS_MAX_STAGES, "felics.h promises at most FELICS_MAX_STAGES stages");
 
-constexpr int SLICES = 12;
+constexpr int SLICES = 12;              // at most; a submission uses lane.nslices of them
 constexpr int EV_PAIRS = SLICES + 2;     // launches of one stage per sub-batch that can be timed
 constexpr int MAX_LANES = 2;            // submissions in flight (felics_submit_batch_device), each with streams and workspace of its own
 
@@ -68,6 +68,7 @@ struct Lane {
     std::vector<uint64_t> r_off, r_len;
     int r_rc = 0;
     // the sub-batch in flight
+    int nslices = SLICES;             // slices its tiles are cut into (see felics_ctx::slices_*)
     Geometry g;
     size_t first_image = 0;
     const void *d_planes = nullptr;
@@ -78,6 +79,11 @@ struct Lane {
 struct felics_ctx {
     int device = -1;
     int next_lane = 0;          // lane of the next felics_submit_batch_device
+    // Slices per sub-batch.  A blocking call has the GPU to itself: more slices let assign / pack follow the
+    // spine closely.  With two submissions in flight the other batch keeps the GPU busy, and every slice costs
+    // a launch and a hand-over per stage: few slices are faster there (measured: 12 -> 5.3, 6 -> 5.1, 3 -> 4.8 ms).
+    int slices_blocking = 6;    // FELICS_SLICES
+    int slices_queued = 3;      // FELICS_SLICES_QUEUED
     bool two_pass = false;      // FELICS_TWO_PASS=1, or a look-back of the single-pass pack gave up once: lengths + pack kernels
     bool test_lookback = false; // FELICS_TEST_LOOKBACK_FAIL=1: pretend the first single-pass submission gave up (tests)
     bool poison = false;        // FELICS_POISON=1: overwrite the workspace before every sub-batch (tests)
@@ -229,6 +235,7 @@ void header_bytes(uint8_t *o, uint32_t w, uint32_t h, int color, int depth) {
 template <typename T, typename ET>
 int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     const Geometry &g = l.g;
+    const int ns = l.nslices;
     const size_t nsamples = (size_t)g.nplanes * g.npix;
     const size_t slots = (size_t)max_event_slots(g);
     int rc;
@@ -308,14 +315,14 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         launch_offsets(f, counts, chain_len, chain_base, (uint32_t *)l.scalars.p, g);
         launch_zero_padding<ET>(f, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, chain_base, chain_len, g);
         HIP_TRY(ctx, hipMemsetAsync(chain_prog, 0, (size_t)g.nplanes * NCTX * 32, f));
-        HIP_TRY(ctx, hipMemsetAsync(l.partial.p, 0, (size_t)SLICES * g.nplanes * NCTX * 8, f));
+        HIP_TRY(ctx, hipMemsetAsync(l.partial.p, 0, (size_t)ns * g.nplanes * NCTX * 8, f));
     }
     uint32_t bounds[SLICES + 1], pbounds[SLICES + 1];  // slice boundaries in sort tiles / pack tiles
-    for (int q = 0; q <= SLICES; q++) {
-        bounds[q] = (uint32_t)((uint64_t)g.sort_tiles * q / SLICES);
-        pbounds[q] = q == SLICES ? g.pack_tiles : std::min<uint32_t>(g.pack_tiles, bounds[q] * (SORT_TILE / PACK_TILE));
+    for (int q = 0; q <= ns; q++) {
+        bounds[q] = (uint32_t)((uint64_t)g.sort_tiles * q / ns);
+        pbounds[q] = q == ns ? g.pack_tiles : std::min<uint32_t>(g.pack_tiles, bounds[q] * (SORT_TILE / PACK_TILE));
     }
-    for (int q = 0; q < SLICES; q++) {
+    for (int q = 0; q < ns; q++) {
         if (bounds[q + 1] != bounds[q]) {
             StageTimer t(ctx, l, ST_SCATTER, f, true);
             launch_scatter<T, ET>(f, d_planes, counts, chain_base, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, g,
@@ -324,9 +331,9 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         HIP_TRY(ctx, hipEventRecord(l.slice_done[q], f));
     }
     // ---- spine stream
-    for (int q = 0; q < SLICES; q++) {
+    for (int q = 0; q < ns; q++) {
         HIP_TRY(ctx, hipStreamWaitEvent(s, l.slice_done[q], 0));
-        if (bounds[q + 1] != bounds[q] || q + 1 == SLICES) {
+        if (bounds[q + 1] != bounds[q] || q + 1 == ns) {
             StageTimer t(ctx, l, ST_SPINE, s, true);
             launch_spine<ET>(s, (const ET *)l.sorted_e.p, (uint32_t *)l.block_state.p, chain_base, chain_len, counts,
                              bounds[q + 1], chain_prog, (uint32_t *)l.block_tag.p, (uint32_t *)l.partial.p, epoch,
@@ -335,9 +342,9 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         HIP_TRY(ctx, hipEventRecord(l.spine_done[q], s));
     }
     // ---- k stream: behind every spine launch, k of the events it published
-    for (int q = 0; q < SLICES; q++) {
+    for (int q = 0; q < ns; q++) {
         HIP_TRY(ctx, hipStreamWaitEvent(ks, l.spine_done[q], 0));
-        if (bounds[q + 1] != bounds[q] || q + 1 == SLICES) {
+        if (bounds[q + 1] != bounds[q] || q + 1 == ns) {
             StageTimer t(ctx, l, ST_ASSIGN, ks, true);
             launch_assign<ET>(ks, (const ET *)l.sorted_e.p, (const uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
                               (const uint32_t *)l.block_state.p, (const uint32_t *)l.scalars.p,
@@ -348,9 +355,9 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     // ---- tail stream: code lengths, bit offsets and (with fixed slots) the packed bits of each slice's tiles
     HIP_TRY(ctx, hipMemsetAsync(plane_carry, 0, (size_t)g.nplanes * 16, tl));
     HIP_TRY(ctx, hipMemsetAsync(d_error, 0, 4, tl));
-    for (int q = 0; q < SLICES; q++) {
+    for (int q = 0; q < ns; q++) {
         HIP_TRY(ctx, hipStreamWaitEvent(tl, l.assign_done[q], 0));
-        const bool last = q + 1 == SLICES;
+        const bool last = q + 1 == ns;
         if (bounds[q + 1] == bounds[q] && !last) continue;
         if (fused) {
             {
@@ -546,7 +553,8 @@ size_t max_images_per_pass(uint64_t npix, uint32_t planes, int depth) {
 // Queues one sub-batch (cnt frames starting at frame `first` of d_pixels) on a lane: geometry, colour
 // transform, and everything run_lane / run_wide enqueue.  Returns without waiting.
 int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const void *d_pixels, uint32_t w, uint32_t h,
-                     int color, int depth, uint8_t *lane_out, uint64_t slot) {
+                     int color, int depth, uint8_t *lane_out, uint64_t slot, int nslices) {
+    l.nslices = std::max(1, std::min(nslices, SLICES));
     const uint32_t planes = color == FELICS_COLOR_RGB ? 3 : 1;
     const uint64_t npix = (uint64_t)w * h;
     const bool wide = depth == FELICS_DEPTH_16;
@@ -664,7 +672,7 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
         while (done < n && !outcome.overflow && !outcome.lookback_failed) {
             const size_t cnt = std::min(per_pass, n - done);
             const size_t first = done + cnt;
-            if ((rc = launch_sub_batch(ctx, l, done, cnt, d_pixels, w, h, color, depth, d_out + done * slot, slot)) != 0) {
+            if ((rc = launch_sub_batch(ctx, l, done, cnt, d_pixels, w, h, color, depth, d_out + done * slot, slot, ctx->slices_blocking)) != 0) {
                 (void)sync_lane(ctx, l);
                 return rc;
             }
@@ -747,6 +755,8 @@ int felics_ctx_create(int device, felics_ctx **out) {
     ctx->poison = getenv("FELICS_POISON") != nullptr;
     ctx->two_pass = getenv("FELICS_TWO_PASS") != nullptr;
     ctx->test_lookback = getenv("FELICS_TEST_LOOKBACK_FAIL") != nullptr;
+    if (const char *e = getenv("FELICS_SLICES")) ctx->slices_blocking = std::max(1, std::min(atoi(e), SLICES));
+    if (const char *e = getenv("FELICS_SLICES_QUEUED")) ctx->slices_queued = std::max(1, std::min(atoi(e), SLICES));
     ctx->trace = getenv("FELICS_TRACE") != nullptr;
     if (const char *e = getenv("FELICS_TIMEOUT_S")) ctx->timeout_s = std::max(1, atoi(e));
     bool ok = hipSetDevice(device) == hipSuccess;
@@ -867,7 +877,7 @@ int felics_submit_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels, 
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         for (int i = 0; i < ST_COUNT; i++) l.ev_used[i] = 0;
         l.p_slot = slot;
-        if ((rc = launch_sub_batch(ctx, l, 0, n, d_pixels, w, h, color, depth, l.p_out, slot)) != 0) {
+        if ((rc = launch_sub_batch(ctx, l, 0, n, d_pixels, w, h, color, depth, l.p_out, slot, ctx->slices_queued)) != 0) {
             (void)sync_lane(ctx, l);
             return rc;
         }

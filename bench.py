@@ -16,8 +16,11 @@ oracle -- a C port of the reference algorithm, the Rust reference cannot be buil
 bounded sample of the same frames on this box's host cores).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,7 +39,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=64, help="frames per rank per step")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
+                    help="BASELINE.json config: 2 = one 4K gray8 frame, 3 = 64 gray8 frames (headline, default), "
+                         "4 = one 4K RGB8 frame, 5 = 64 RGB8 frames per GPU (one GPU's share of the 512-frame job)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per rank per step (default: what --config says)")
     ap.add_argument("--kind", default="S1", choices=["S1", "S2", "S3"])
     ap.add_argument("--rgb", action="store_true", help="RGB8 frames (config 4/5) instead of gray8")
     ap.add_argument("--depth16", action="store_true", help="16-bit grayscale frames (side measurement, not the headline)")
@@ -47,7 +53,26 @@ def parse():
     ap.add_argument("--synchronous", action="store_true", help="time the blocking entry point (one batch at a time)")
     ap.add_argument("--no-blocking-extra", action="store_true",
                     help="skip the three extra blocking-call steps after the timed region (rocprofv3 runs: keeps the kernel averages those of the timed steps)")
-    return ap.parse_args()
+    ap.add_argument("--no-side-configs", action="store_true", help="skip the short config 2 / config 4 legs of the default run")
+    args = ap.parse_args()
+    if args.config in (4, 5):
+        args.rgb = True
+    if args.frames is None:
+        args.frames = 1 if args.config in (2, 4) else 64
+    return args
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start N ranks as a CHILD process (this parent has made no
+    GPU call yet) and pass its output and exit code on.  A run never reports fewer GPUs than it was asked for."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(frames_np, budget_s):
@@ -87,6 +112,10 @@ def cpu_baseline(frames_np, budget_s):
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import numpy as np
     import torch
     import felics_amd
@@ -95,8 +124,10 @@ def main():
     from felics_amd import dist as fdist
 
     rank, world, local = fdist.env_rank()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:  # never print n_gpus different from what was asked for
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if torch.cuda.device_count() < world or local >= torch.cuda.device_count():
+        raise SystemExit("--gpus %d but this node shows %d GPU(s)" % (args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     group = fdist.Group("nccl", dev)  # RCCL; barrier + MAX of the time only, no data-path collective
@@ -152,7 +183,12 @@ def main():
         if got != want:
             raise SystemExit("rank %d frame %d: GPU stream differs from the oracle" % (rank, i))
         checked += 1
-    ref_sum = int(host.astype(np.uint64).sum())
+
+    def stream_digests(buf):  # one digest per stream, in order: a reordered or shifted stream cannot pass
+        h = buf[: int(offs[-1] + lens[-1])].cpu().numpy()
+        return [hashlib.blake2b(h[int(offs[i]): int(offs[i] + lens[i])].tobytes(), digest_size=16).hexdigest() for i in range(F)]
+
+    ref_digests = stream_digests(d_out)
     total_bytes = int(lens.sum())
 
     for _ in range(args.warmup):
@@ -196,8 +232,7 @@ def main():
 
     # the timed steps must have produced the same bytes as the checked one (both output buffers)
     for o in (d_outs[: max(1, min(depth_q, args.steps))] if not args.synchronous else d_outs[:1]):
-        host2 = o[: int(offs[-1] + lens[-1])].cpu().numpy()
-        if int(host2.astype(np.uint64).sum()) != ref_sum:
+        if stream_digests(o) != ref_digests:
             raise SystemExit("rank %d: output changed between steps" % rank)
     # for the record: a few steps through the blocking entry point (one batch at a time)
     sync_ms = None
@@ -207,6 +242,39 @@ def main():
         for _ in range(3):
             step()
         sync_ms = (time.perf_counter() - t1) / 3 * 1e3
+
+    # Configs 2 and 4 (one 4K gray8 / RGB8 frame per call) ride along with the default run so that they are
+    # driver-timed too: a short stream of single-frame submissions through the queue, and blocking calls.
+    side = None
+    if rank == 0 and args.config == 3 and not args.no_side_configs and not args.depth16 and not args.rgb and (W, H) == (W4K, H4K):
+        side = {}
+        for name, rgbf in (("config2_one_4k_gray8_frame", False), ("config4_one_4k_rgb8_frame", True)):
+            fr = (synth_torch.rgb8(W, H, 0, device=dev) if rgbf else frames[0]).contiguous()
+            ch = 3 if rgbf else 1
+            outs = [torch.empty(int(npix * ch * 1.25) + (1 << 20), dtype=torch.uint8, device=dev) for _ in range(depth_q)]
+            o1, l1 = enc.compress_batch_device(fr.data_ptr(), 1, W, H, int(rgbf), 0, outs[0].data_ptr(), outs[0].numel())
+            got = outs[0][int(o1[0]): int(o1[0] + l1[0])].cpu().numpy().tobytes()
+            if got != oracle.compress(fr.cpu().numpy()):
+                raise SystemExit("%s: GPU stream differs from the oracle" % name)
+            reps = 20
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                enc.compress_batch_device(fr.data_ptr(), 1, W, H, int(rgbf), 0, outs[0].data_ptr(), outs[0].numel())
+            blocking = (time.perf_counter() - t1) / reps
+            t1 = time.perf_counter()
+            q = []
+            for i in range(reps):
+                if len(q) == depth_q:
+                    enc.wait_batch(q.pop(0))
+                q.append(enc.submit_batch_device(fr.data_ptr(), 1, W, H, int(rgbf), 0, outs[i % depth_q].data_ptr(), outs[i % depth_q].numel()))
+            while q:
+                enc.wait_batch(q.pop(0))
+            queued = (time.perf_counter() - t1) / reps
+            side[name] = {"ms_per_frame_blocking_call": round(blocking * 1e3, 3), "MPix_s_blocking_call": round(npix / blocking / 1e6, 1),
+                          "ms_per_frame_queued": round(queued * 1e3, 3), "MPix_s_queued": round(npix / queued / 1e6, 1),
+                          "frac_of_hbm_peak_queued": round(npix * ch / queued / 1e9 / HBM_PEAK_GBS, 5),
+                          "calls": reps, "byte_compared_with_oracle": True}
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -223,15 +291,27 @@ def main():
             per_launch_ms = stage_ms[dom] / launches
             per_launch_bytes = alg_bytes / launches
             achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC FETCH_SIZE + WRITE_SIZE of this command
-            if os.path.exists(tpath) and not args.rgb and not args.depth16 and args.kind == "S1" and F == 64 and (W, H) == (W4K, H4K):
-                traffic = json.load(open(tpath)).get("k_" + dom, {}).get("hbm_bytes_per_step")
-                traffic = int(traffic / launches) if traffic else None
+            # PMC figures (FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes of profiles/tools/collect.sh) are a
+            # property of a build on this exact workload: used only if the file was made from the sources
+            # this library was built from, otherwise null.
+            traffic = valu = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            headline = not args.rgb and not args.depth16 and args.kind == "S1" and F == 64 and (W, H) == (W4K, H4K)
+            if os.path.exists(tpath) and headline:
+                from felics_amd import build as fbuild
+
+                tj = json.load(open(tpath))
+                if tj.get("_source_sha256") == fbuild.source_hash():
+                    t = tj.get("k_" + dom, {}).get("hbm_bytes_per_step")
+                    traffic = int(t / launches) if t else None
+                    insts = tj.get("_valu_wave_insts_per_step")
+                    if insts:  # wave64 VALU instructions per step against 1024 SIMDs x 2.4 GHz / 2 cycles per instruction
+                        valu = {"wave_insts_per_step": int(insts), "issue_peak_per_s": 1.2288e12,
+                                "frac_of_issue_peak": round(insts / 1.2288e12 / (ms_per_step * 1e-3), 4)}
             roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(per_launch_ms, 4),
-                        "launches_per_step": launches}
+                        "launches_per_step": launches, "valu": valu}
         # the same figure for every stage (HIP-event brackets; on the low-priority streams they include the wait
         # for free compute resources, which rocprof's kernel begin / end timestamps do not)
         per_stage = {}
@@ -256,18 +336,19 @@ def main():
             "config": {"workload": "batch of %d synthetic %s %dx%d %d-bit %s frames per GPU, resident in HBM"
                                    % (F, "S1-RGB" if args.rgb else args.kind, W, H, 16 if args.depth16 else 8,
                                       "RGB" if args.rgb else "grayscale"),
-                       "frames_per_gpu": F, "width": W, "height": H, "channels": channels,
+                       "baseline_config": args.config, "frames_per_gpu": F, "width": W, "height": H, "channels": channels,
                        "sharding": "frames split across ranks, no collective"},
             "roofline": roofline,
             "cpu_baseline": cpu1,
             "cpu_baseline_all_cores": cpum,
+            "other_configs": side,
             "pipeline": {"achieved_GBs": round(pipeline_gbs, 2), "frac_of_hbm_peak": round(pipeline_gbs / HBM_PEAK_GBS, 5),
                          "stage_ms_sum_of_launches": {k: round(v, 4) for k, v in stage_ms.items()},
                          "per_stage": per_stage,
                          "submission": "blocking calls" if args.synchronous else "%d batches in flight (submit ahead, wait in order)" % depth_q,
                          "ms_per_step_blocking_calls": None if sync_ms is None else round(sync_ms, 3),
                          "note": "the stages follow each other slice by slice on four HIP streams; launches overlap, so the sums exceed ms_per_step"},
-            "parity": {"frames_byte_compared_with_oracle": checked, "output_checksum_stable": True,
+            "parity": {"frames_byte_compared_with_oracle": checked, "streams_digest_checked_after_timed_steps": F,
                        "compressed_bytes_per_step_rank0": total_bytes,
                        "bits_per_pixel": round(total_bytes * 8 / (F * npix), 4)},
         }

@@ -4,7 +4,8 @@ Layout: csrc/ (HIP kernels, C ABI, host decoder, command lines), api.py (host mi
 reference's public surface over ctypes), synth.py (the benchmark's synthetic frames).
 """
 from .api import (ColorType, DecompressionError, Encoder, FelicsError, Header, PixelDepth,  # noqa: F401
-                  compress, compress_image, decompress, decompress_image, read_header, write_header)
+                  compress, compress_image, decompress, decompress_image, decompress_with_header, read_header,
+                  write_header)
 
 __all__ = ["ColorType", "DecompressionError", "Encoder", "FelicsError", "Header", "PixelDepth", "compress",
-           "compress_image", "decompress", "decompress_image", "read_header", "write_header"]
+           "compress_image", "decompress", "decompress_image", "decompress_with_header", "read_header", "write_header"]

@@ -59,6 +59,11 @@ class _CHeader(C.Structure):
                 ("width", C.c_uint32), ("height", C.c_uint32)]
 
 
+class _CStats(C.Structure):
+    _fields_ = [("submissions", C.c_uint64), ("slot_overflows", C.c_uint64), ("lookback_fallbacks", C.c_uint64),
+                ("two_pass", C.c_int), ("failed", C.c_int)]
+
+
 class Header:  # format.rs:44-49
     def __init__(self, color_type, pixel_depth, width, height):
         self.color_type = ColorType(color_type)
@@ -80,7 +85,7 @@ EXPORTS = [
     "felics_read_header", "felics_write_header",
     "felics_decompress", "felics_strerror", "felics_last_error", "felics_set_profiling",
     "felics_stage_count", "felics_stage_name", "felics_get_stage_ms", "felics_get_stage_launches",
-    "felics_lane_count",
+    "felics_lane_count", "felics_decompress_with_header", "felics_get_stats",
 ]
 
 _lib = None
@@ -131,6 +136,8 @@ def lib():
     L.felics_read_header.argtypes = [vp, sz, C.POINTER(_CHeader)]
     L.felics_write_header.argtypes = [C.POINTER(_CHeader), vp, sz]
     L.felics_decompress.argtypes = [vp, sz, vp, sz, C.POINTER(_CHeader)]
+    L.felics_decompress_with_header.argtypes = [vp, sz, C.POINTER(_CHeader), vp, sz]
+    L.felics_get_stats.argtypes = [vp, C.POINTER(_CStats)]
     L.felics_strerror.argtypes = [C.c_int]
     L.felics_strerror.restype = C.c_char_p
     L.felics_last_error.argtypes = [vp]
@@ -257,6 +264,12 @@ class Encoder:
             self._raise(rc)
         return offs, lens
 
+    def stats(self):
+        """felics_get_stats: batches redone (slot overflow, look-back fallback), slow-path / failed flags."""
+        st = _CStats()
+        lib().felics_get_stats(self._h, C.byref(st))
+        return {k: int(getattr(st, k)) for k, _ in _CStats._fields_}
+
     def set_profiling(self, on):
         lib().felics_set_profiling(self._h, int(bool(on)))
 
@@ -328,7 +341,7 @@ def decompress_image(from_):
     planes = 3 if ch.color_type else 1
     dt = np.uint16 if ch.pixel_depth else np.uint8
     # a corrupt header must not make us allocate before the stream proves it holds that many pixels
-    if ch.width * ch.height * planes > max(len(arr), 1) * 8 * 4096:
+    if ch.width * ch.height * planes > max(len(arr), 1) * 8 + 2 * planes:  # a pixel costs at least one bit
         raise DecompressionError(-1)
     shape = (ch.height, ch.width, 3) if planes == 3 else (ch.height, ch.width)
     out = np.zeros(shape, dtype=dt)
@@ -342,6 +355,24 @@ def decompress_image(from_):
 def decompress(from_):
     """CompressDecompress::decompress (traits.rs:57-64)."""
     return decompress_image(from_)
+
+
+def decompress_with_header(from_, header):
+    """CompressDecompress::decompress_with_header (traits.rs:53-56): `from_` is positioned behind the header."""
+    data = from_.read() if hasattr(from_, "read") else bytes(from_)
+    arr = np.frombuffer(data, dtype=np.uint8)
+    planes = 3 if int(header.color_type) else 1
+    dt = np.uint16 if int(header.pixel_depth) else np.uint8
+    if header.width * header.height * planes > max(len(arr), 1) * 8 + 2 * planes:  # a pixel costs at least one bit
+        raise DecompressionError(-1)
+    shape = (header.height, header.width, 3) if planes == 3 else (header.height, header.width)
+    out = np.zeros(shape, dtype=dt)
+    ch = _CHeader(int(header.color_type), int(header.pixel_depth), header.width, header.height)
+    rc = lib().felics_decompress_with_header(arr.ctypes.data if len(arr) else None, len(arr), C.byref(ch),
+                                             out.ctypes.data if out.size else None, out.nbytes)
+    if rc != 0:
+        raise DecompressionError(rc)
+    return out
 
 
 def decompress_bytes(data):

@@ -24,6 +24,19 @@ def sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [inc]
 
 
+def source_hash():
+    """sha256 over the native sources (csrc/* and include/felics.h, by name and content): names a build
+    independently of git history, so measurements (profiles/traffic.json) can say which build they belong to."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sources():
+        if os.path.isfile(path):
+            h.update(os.path.basename(path).encode() + b"\0")
+            h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
 def build(force=False, quiet=True):
     """make -C csrc all; returns the path of libfelics.so."""
     targets = [LIB, os.path.join(OUT, "cfelics"), os.path.join(OUT, "dfelics")]

@@ -89,6 +89,11 @@ struct felics_ctx {
     bool poison = false;        // FELICS_POISON=1: overwrite the workspace before every sub-batch (tests)
     bool trace = false;         // FELICS_TRACE=1: synchronise and report after every stage (debugging)
     int timeout_s = 120;        // FELICS_TIMEOUT_S: give up waiting for a submission after this long
+    // A wait for the GPU timed out: kernels of this context may still be running (or never return), so nothing
+    // of it may be reused or freed.  Every later call fails with FELICS_E_HIP; the caller should exit (or run
+    // further work in a fresh process).
+    bool failed = false;
+    felics_stats stats = {};
     Lane lanes[MAX_LANES];
     std::string err;
     bool profiling = false;
@@ -123,7 +128,9 @@ int wait_event(felics_ctx *ctx, hipEvent_t ev, const char *what) {
         if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
         if ((spins & 1023) == 1023 &&
             std::chrono::steady_clock::now() - t0 > std::chrono::seconds(ctx->timeout_s)) {
-            ctx->err = std::string(what) + ": timed out waiting for the GPU";
+            ctx->err = std::string(what) + ": timed out waiting for the GPU; the context is unusable from here on";
+            ctx->failed = true;
+            ctx->stats.failed = 1;
             return FELICS_E_HIP;
         }
     }
@@ -555,6 +562,7 @@ size_t max_images_per_pass(uint64_t npix, uint32_t planes, int depth) {
 int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const void *d_pixels, uint32_t w, uint32_t h,
                      int color, int depth, uint8_t *lane_out, uint64_t slot, int nslices) {
     l.nslices = std::max(1, std::min(nslices, SLICES));
+    ctx->stats.submissions++;
     const uint32_t planes = color == FELICS_COLOR_RGB ? 3 : 1;
     const uint64_t npix = (uint64_t)w * h;
     const bool wide = depth == FELICS_DEPTH_16;
@@ -716,9 +724,13 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
             // kernels holding the GPU, most likely): this context packs in two passes from now on.
             if ((rc = sync_lane(ctx, l)) != 0) return rc;
             ctx->two_pass = true;
+            ctx->stats.lookback_fallbacks++;
+            ctx->stats.two_pass = 1;
+            ctx->err = "a tile gave up waiting for its predecessors: this context now packs with the two-pass kernels (slower)";
             continue;
         }
         if (!outcome.overflow) break;
+        ctx->stats.slot_overflows++;
         slot = 0;  // a stream outgrew its slot: do the batch again with exact placement
     }
     collect_timing(ctx, l);
@@ -750,7 +762,9 @@ int felics_ctx_create(int device, felics_ctx **out) {
     if (!ctx) return FELICS_E_IO;
     ctx->device = device;
     // Four streams want four hardware queues of their own; ROCm's default is 4 per process and the
-    // caller's stream takes one.  Only effective if the HIP runtime has not been initialised yet.
+    // caller's stream takes one.  Only effective if the HIP runtime has not been initialised yet, and never
+    // overrides a value the process already has (overwrite = 0): a host application that manages its own
+    // queues sets GPU_MAX_HW_QUEUES itself (felics_amd/api.py and bench.py do so before loading anything).
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
     ctx->poison = getenv("FELICS_POISON") != nullptr;
     ctx->two_pass = getenv("FELICS_TWO_PASS") != nullptr;
@@ -793,6 +807,10 @@ int felics_ctx_create(int device, felics_ctx **out) {
 
 void felics_ctx_destroy(felics_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->failed) {  // kernels may still hold the streams and the workspace: leave everything to process exit
+        delete ctx;
+        return;
+    }
     (void)hipSetDevice(ctx->device);
     for (Lane &l : ctx->lanes) {
         if (l.front) (void)hipStreamSynchronize(l.front);
@@ -836,6 +854,7 @@ size_t felics_max_compressed_size(uint32_t w, uint32_t h, int color, int depth) 
 int felics_compress_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, uint32_t h, int color,
                                  int depth, void *d_out, size_t d_out_cap, uint64_t *offsets, uint64_t *lens) {
     if (!ctx || !offsets || !lens || !d_out || (!d_pixels && n && (uint64_t)w * h)) return FELICS_E_INVALID_ARGUMENT;
+    if (ctx->failed) return FELICS_E_HIP;
     int rc = check_args(w, h, color, depth);
     if (rc) return rc;
     if (n == 0) return FELICS_OK;
@@ -847,6 +866,7 @@ int felics_compress_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels
 int felics_submit_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w, uint32_t h, int color,
                                int depth, void *d_out, size_t d_out_cap, int *ticket) {
     if (!ctx || !ticket || !d_out || n == 0 || (!d_pixels && (uint64_t)w * h)) return FELICS_E_INVALID_ARGUMENT;
+    if (ctx->failed) return FELICS_E_HIP;
     int rc = check_args(w, h, color, depth);
     if (rc) return rc;
     const int L = ctx->next_lane;
@@ -890,8 +910,15 @@ int felics_submit_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels, 
 
 int felics_wait_batch(felics_ctx *ctx, int ticket, uint64_t *offsets, uint64_t *lens) {
     if (!ctx || ticket < 0 || ticket >= MAX_LANES || !offsets || !lens) return FELICS_E_INVALID_ARGUMENT;
+    if (ctx->failed) return FELICS_E_HIP;
     Lane &l = ctx->lanes[ticket];
     if (!l.pending) return FELICS_E_INVALID_ARGUMENT;
+    if (!l.finished) {
+        // the lane stays marked busy until its kernels are known to have finished: after a timeout nothing may
+        // reuse or free its workspace
+        const int wrc = wait_event(ctx, l.sized, "stream sizes");
+        if (wrc) return wrc;
+    }
     l.pending = false;
     if (l.finished) {
         for (size_t i = 0; i < l.p_n; i++) {
@@ -901,7 +928,6 @@ int felics_wait_batch(felics_ctx *ctx, int ticket, uint64_t *offsets, uint64_t *
         return l.r_rc;
     }
     int rc;
-    if ((rc = wait_event(ctx, l.sized, "stream sizes")) != 0) return rc;
     const SlotOutcome o = read_sizes(ctx, l, l.p_depth == FELICS_DEPTH_16, l.p_slot, offsets, lens);
     if (!o.lookback_failed && !o.overflow) {
         collect_timing(ctx, l);
@@ -909,7 +935,14 @@ int felics_wait_batch(felics_ctx *ctx, int ticket, uint64_t *offsets, uint64_t *
     }
     // the rare cases: pack again on this lane, synchronously (two-pass kernels / exact placement)
     if ((rc = sync_lane(ctx, l)) != 0) return rc;
-    if (o.lookback_failed) ctx->two_pass = true;
+    if (o.lookback_failed) {
+        ctx->two_pass = true;
+        ctx->stats.lookback_fallbacks++;
+        ctx->stats.two_pass = 1;
+        ctx->err = "a tile gave up waiting for its predecessors: this context now packs with the two-pass kernels (slower)";
+    } else {
+        ctx->stats.slot_overflows++;
+    }
     return encode_device(ctx, l, l.p_n, l.p_pixels, l.p_w, l.p_h, l.p_color, l.p_depth, l.p_out, l.p_cap, offsets, lens,
                          nullptr, o.overflow && !o.lookback_failed);
 }
@@ -917,6 +950,7 @@ int felics_wait_batch(felics_ctx *ctx, int ticket, uint64_t *offsets, uint64_t *
 int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, uint32_t w, uint32_t h, int color,
                           int depth, uint8_t *const *outs, const size_t *caps, size_t *lens) {
     if (!ctx || (n && (!pixels || !outs || !caps || !lens))) return FELICS_E_INVALID_ARGUMENT;
+    if (ctx->failed) return FELICS_E_HIP;
     int rc = check_args(w, h, color, depth);
     if (rc) return rc;
     if (n == 0) return FELICS_OK;
@@ -1002,6 +1036,14 @@ const char *felics_last_error(const felics_ctx *ctx) { return ctx ? ctx->err.c_s
 int felics_set_profiling(felics_ctx *ctx, int enabled) {
     if (!ctx) return FELICS_E_INVALID_ARGUMENT;
     ctx->profiling = enabled != 0;
+    return FELICS_OK;
+}
+
+int felics_get_stats(const felics_ctx *ctx, felics_stats *out) {
+    if (!ctx || !out) return FELICS_E_INVALID_ARGUMENT;
+    *out = ctx->stats;
+    out->two_pass = ctx->two_pass ? 1 : 0;
+    out->failed = ctx->failed ? 1 : 0;
     return FELICS_OK;
 }
 

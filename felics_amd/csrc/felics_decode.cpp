@@ -234,28 +234,45 @@ int felics_read_header(const uint8_t *in, size_t len, felics_header *hdr) {
     return FELICS_OK;
 }
 
-int felics_decompress(const uint8_t *in, size_t len, void *pixels, size_t pixels_cap, felics_header *hdr_out) {
-    felics_header hdr;
-    int rc = felics_read_header(in, len, &hdr);
-    if (rc) return rc;
-    if (hdr_out) *hdr_out = hdr;
+// decompress_with_header (traits.rs:53-56; impls compression.rs:284-314, :373-409): `in` is the bit stream that
+// follows the 14 header bytes.  Nothing is allocated before the header's claims have been checked against
+// the caller's buffer and against the stream itself (a pixel costs at least one bit).
+int felics_decompress_with_header(const uint8_t *in, size_t len, const felics_header *hdr_in, void *pixels,
+                                  size_t pixels_cap) {
+    if (!hdr_in || (!in && len)) return FELICS_E_INVALID_ARGUMENT;
+    const felics_header hdr = *hdr_in;
+    if (hdr.color_type > 1) return FELICS_E_INVALID_COLOR_TYPE;
+    if (hdr.pixel_depth > 1) return FELICS_E_INVALID_PIXEL_DEPTH;
     const unsigned planes = hdr.color_type == FELICS_COLOR_RGB ? 3 : 1;
+    const size_t bps = hdr.pixel_depth == FELICS_DEPTH_8 ? 1 : 2;
+    const uint64_t npix = (uint64_t)hdr.width * hdr.height;
+    if (npix > 0xFFFFFFFFull) return FELICS_E_INVALID_DIMENSIONS;
+    if (npix * planes * bps > pixels_cap) return FELICS_E_BUFFER_TOO_SMALL;
+    if (npix && !pixels) return FELICS_E_INVALID_ARGUMENT;
+    // every plane starts with two 32-bit values; every further pixel takes at least one flag bit
+    if (len < 8ull * planes) return FELICS_E_IO;
+    if (npix > 2 && (npix - 2) * planes > (uint64_t)(len - 8ull * planes) * 8ull) return FELICS_E_IO;
     const Options opt = hdr.pixel_depth == FELICS_DEPTH_8 ? Options{255u * 2u, 6} : Options{65535u * 2u, 15};
-    BitReader br(in + FELICS_HEADER_BYTES, len - FELICS_HEADER_BYTES);
+    BitReader br(in, len);
     std::vector<int32_t> ch[3];
     try {
         for (unsigned c = 0; c < planes; c++) {
-            rc = decode_plane(br, hdr.width, hdr.height, opt, ch[c]);
+            const int rc = decode_plane(br, hdr.width, hdr.height, opt, ch[c]);
             if (rc) return rc;
         }
     } catch (const std::bad_alloc &) {
         return FELICS_E_INVALID_DIMENSIONS;
     }
-    const size_t bps = hdr.pixel_depth == FELICS_DEPTH_8 ? 1 : 2;
-    if (ch[0].size() * planes * bps > pixels_cap) return FELICS_E_BUFFER_TOO_SMALL;
     if (ch[0].empty()) return FELICS_OK;
-    if (!pixels) return FELICS_E_INVALID_ARGUMENT;
     return bps == 1 ? store_pixels(ch, planes, (uint8_t *)pixels, 255) : store_pixels(ch, planes, (uint16_t *)pixels, 65535);
+}
+
+int felics_decompress(const uint8_t *in, size_t len, void *pixels, size_t pixels_cap, felics_header *hdr_out) {
+    felics_header hdr;
+    const int rc = felics_read_header(in, len, &hdr);
+    if (rc) return rc;
+    if (hdr_out) *hdr_out = hdr;
+    return felics_decompress_with_header(in + FELICS_HEADER_BYTES, len - FELICS_HEADER_BYTES, &hdr, pixels, pixels_cap);
 }
 
 }  // extern "C"

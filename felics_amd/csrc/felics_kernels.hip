@@ -588,7 +588,7 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
 // one block that has events in place but is not full yet (partial[chain] = {block, events}).  Later spine
 // launches may already be running: they tag other blocks and rewrite a partial block's record with the
 // same values, so nothing read here is in flux.  Waves scan 64 tags / 64 list entries at a time.
-constexpr uint32_t TAG_SLICE_BITS = 5;  // tag = epoch << 4 | slice
+constexpr uint32_t TAG_SLICE_BITS = 5;  // tag = epoch << 5 | slice
 
 // what a wave needs to serve one block: the block's record and, per lane, its event and its pixel
 struct BlockIn {

@@ -109,9 +109,14 @@ std::string read_tiff(const std::vector<uint8_t> &buf, Image &img) {
     if (photo > 2) return "TIFF: unsupported photometric interpretation " + std::to_string(photo);
     if (!tags.count(273)) return "TIFF: no strip offsets (tiled files are not supported)";
     const std::vector<uint32_t> &offs = tags[273];
-    const uint32_t rps = std::min(first(278, H), H);
+    // RowsPerStrip defaults to "all rows" (2^32 - 1); zero is not a strip height: read it the same way
+    uint32_t rps = first(278, H);
+    if (rps == 0 || rps > H) rps = H;
     const size_t bps = bits / 8, row = (size_t)W * spp * bps;
     if ((uint64_t)row * H > (1ull << 34)) return "TIFF: image too large";
+    // uncompressed samples live in the file: an image larger than the file is a forged header, refused before
+    // anything is allocated for it
+    if ((uint64_t)row * H > buf.size()) return "TIFF: the file is too short for the image it describes";
     const size_t nstrips = (H + rps - 1) / rps;
     if (offs.size() < nstrips) return "TIFF: strip table too short";
     img.width = W;

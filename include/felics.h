@@ -125,9 +125,27 @@ int felics_write_header(const felics_header *hdr, uint8_t *out, size_t cap);
 int felics_decompress(const uint8_t *in, size_t len, void *pixels, size_t pixels_cap,
                       felics_header *hdr);
 
+/* Replaces `CompressDecompress::decompress_with_header(from, &Header)` (traits.rs:53-56; compression.rs:284-314,
+ * :373-409): the caller has read (or knows) the header; `in` points at the bit stream BEHIND the 14 header bytes.
+ * The header's claims are checked against pixels_cap and against the stream length before anything is allocated. */
+int felics_decompress_with_header(const uint8_t *in, size_t len, const felics_header *hdr, void *pixels,
+                                  size_t pixels_cap);
+
 /* Text for a code above; for FELICS_E_HIP felics_last_error(ctx) has the HIP message. */
 const char *felics_strerror(int code);
 const char *felics_last_error(const felics_ctx *ctx);
+
+/* What has happened to a context that the return codes do not say: how often it had to redo a batch, and
+ * whether it is on a slower path or unusable.  (A look-back / hand-off that gives up -- e.g. another process
+ * holding the GPU for a second -- moves the context to the two-pass kernels for good; felics_last_error says so.) */
+typedef struct felics_stats {
+    uint64_t submissions;        /* sub-batches queued so far */
+    uint64_t slot_overflows;     /* batches redone with exact placement: a stream outgrew its fixed slot */
+    uint64_t lookback_fallbacks; /* batches redone because a tile gave up waiting for its predecessors */
+    int two_pass;                /* 1: the context packs with the two-pass kernels from now on (slower) */
+    int failed;                  /* 1: a wait for the GPU timed out; every further call returns FELICS_E_HIP */
+} felics_stats;
+int felics_get_stats(const felics_ctx *ctx, felics_stats *out);
 
 /* ---- measurement hooks (bench.py) ----
  * With profiling on, every kernel launch of the next submission gets a start / stop HIP event on the

@@ -161,6 +161,41 @@ def test_baseline_batch_round_trip(enc, oracle):
         assert back.dtype == np.uint8 and (back == f).all(), i
 
 
+def test_config5_rgb_batch_share(enc, oracle):
+    """BASELINE config 5, one GPU's share: 64 synthetic 4K RGB8 frames in ONE felics_compress_batch_device
+    submission (frames generated in HBM, streams left in HBM).  Four streams are byte-compared with the oracle,
+    all 64 are decoded back to their frames, and every stream carries the right header."""
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+
+    import felics_amd
+    import torch
+    from felics_amd import synth_torch
+
+    n, w, h = 64, 3840, 2160
+    frames = torch.empty((n, h, w, 3), dtype=torch.uint8, device="cuda")
+    for f in range(n):
+        frames[f] = synth_torch.rgb8(w, h, f)
+    cap = int(n * w * h * 3 * 1.25) + (1 << 20)
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    offs, lens = enc.compress_batch_device(frames.data_ptr(), n, w, h, 1, 0, d_out.data_ptr(), cap)
+    assert all(int(o) % 16 == 0 for o in offs) and list(offs) == sorted(offs)
+    host = d_out[: int(offs[-1] + lens[-1])].cpu().numpy()
+    streams = [host[int(offs[i]): int(offs[i] + lens[i])].tobytes() for i in range(n)]
+    for i in (0, 22, 41, 63):
+        assert streams[i] == oracle.compress(frames[i].cpu().numpy()), i
+
+    def back(i):
+        hdr = felics_amd.read_header(io.BytesIO(streams[i][:14]))
+        assert (hdr.width, hdr.height, int(hdr.color_type), int(hdr.pixel_depth)) == (w, h, 1, 0)
+        img = felics_amd.decompress_image(io.BytesIO(streams[i]))  # ctypes releases the GIL inside the decoder
+        return bool((torch.from_numpy(img) == frames[i].cpu()).all())
+
+    with ThreadPoolExecutor(max_workers=12) as ex:
+        assert all(ex.map(back, range(n)))
+
+
 def test_device_resident_batch(enc, oracle):
     """felics_compress_batch_device with torch holding the HBM buffers (plumbing only)."""
     import torch

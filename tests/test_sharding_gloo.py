@@ -73,3 +73,25 @@ def test_two_ranks_gloo(tmp_path):
                        capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert ("DIGEST " + want) in r.stdout
+
+
+def test_bench_multi_gpu_command_cannot_degrade():
+    """`python bench.py --gpus 2` outside torchrun starts two ranks itself (as a child process) or fails; it
+    never prints a line for fewer GPUs than asked.  No GPU here: the ranks must fail and the command with them."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--cpu-seconds", "0"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert r.returncode == 0 and '"n_gpus": 2' in r.stdout
+    else:
+        assert r.returncode != 0, r.stdout[-2000:]
+        assert '"n_gpus"' not in r.stdout
+    # a rank count that disagrees with --gpus is refused as well
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True,
+                       text=True, timeout=300, cwd=ROOT, env=env2)
+    assert r.returncode != 0 and '"n_gpus"' not in r.stdout

@@ -60,7 +60,7 @@ class _CHeader(C.Structure):
 
 
 class _CStats(C.Structure):
-    _fields_ = [("submissions", C.c_uint64), ("slot_overflows", C.c_uint64), ("lookback_fallbacks", C.c_uint64),
+    _fields_ = [("submissions", C.c_uint64), ("fused_submissions", C.c_uint64), ("slot_overflows", C.c_uint64), ("lookback_fallbacks", C.c_uint64),
                 ("two_pass", C.c_int), ("failed", C.c_int)]
 
 

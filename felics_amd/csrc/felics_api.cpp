@@ -21,9 +21,9 @@ using namespace felics;
 namespace {
 
 enum Stage { ST_PLANES = 0, ST_HIST, ST_OFFSETS, ST_SCATTER, ST_SPINE, ST_ASSIGN, ST_LENGTHS, ST_BITSCAN, ST_ZERO, ST_PACK,
-             ST_WIDE_KEYS, ST_WIDE_SORT, ST_WIDE_CHAINS, ST_COUNT };
+             ST_WIDE_KEYS, ST_WIDE_SORT, ST_WIDE_CHAINS, ST_STRIPE, ST_COUNT };
 const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "spine", "assign", "lengths", "bitscan", "zero", "pack",
-                                     "wide_keys", "wide_sort", "wide_chains"};
+                                     "wide_keys", "wide_sort", "wide_chains", "stripe"};
 static_assert(ST_COUNT <= FELICS_MAX_STAGES, "felics.h promises at most FELICS_MAX_STAGES stages");
 
 constexpr int SLICES = 12;              // at most; a submission uses lane.nslices of them
@@ -54,6 +54,8 @@ struct Lane {
     DevBuf planes, counts, chain_len, chain_base, chain_prog, scalars, sorted_e, pix_of, k_map, block_state, group_bits,
         tile_bits, tile_bitoff, plane_sums, image_bytes, image_off, partial, block_tag, status, edge_first, edge_last, pscratch;
     DevBuf wkeys[2], wvals[2], e_of, heads, sort_temp;  // 16-bit samples: sort records, Rice operands, chain heads
+    DevBuf s_ctl, s_table, s_status;                     // fused tile kernel: control block, estimator tables, look-back words
+    bool ran_stripe = false;                             // the sub-batch in flight went through the fused tile kernel
     uint32_t epoch = 0;               // sub-batches this lane has run: block tags are (epoch, slice)
     // the submission in flight on this lane (felics_submit_batch_device .. felics_wait_batch)
     bool pending = false;
@@ -84,7 +86,11 @@ struct felics_ctx {
     // a launch and a hand-over per stage: few slices are faster there (measured: 12 -> 5.3, 6 -> 5.1, 3 -> 4.8 ms).
     int slices_blocking = 6;    // FELICS_SLICES
     int slices_queued = 3;      // FELICS_SLICES_QUEUED
+    bool stripe = true;         // 8-bit frames with fixed output slots go through the fused tile kernel (felics_stripe.hip);
+                                // FELICS_PIPELINE=classic, or a hand-off of that kernel that gave up once, selects the multi-kernel pipeline
+    uint32_t stripe_wgs = 256;  // workgroups of the persistent kernel: one per CU (its LDS fills a CU); FELICS_STRIPE_WGS
     bool two_pass = false;      // FELICS_TWO_PASS=1, or a look-back of the single-pass pack gave up once: lengths + pack kernels
+    bool test_stripe_fail = false; // FELICS_TEST_STRIPE_FAIL=1: pretend the first fused-kernel submission gave up (tests)
     bool test_lookback = false; // FELICS_TEST_LOOKBACK_FAIL=1: pretend the first single-pass submission gave up (tests)
     bool poison = false;        // FELICS_POISON=1: overwrite the workspace before every sub-batch (tests)
     bool trace = false;         // FELICS_TRACE=1: synchronise and report after every stage (debugging)
@@ -417,6 +423,94 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     return FELICS_OK;
 }
 
+// The fused tile kernel (felics_stripe.hip): one persistent launch per sub-batch takes every tile from pixels to
+// packed bits inside LDS.  Needs fixed output slots (like the single-pass pack); same contract as run_lane
+// towards the caller: sizes and the error word land in the lane's pinned buffer, `sized` is recorded behind them.
+template <typename T>
+int run_stripe(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
+    const Geometry &g = l.g;
+    const uint32_t ntiles = (uint32_t)(((uint64_t)g.npix + StripeCfg<T>::TILE - 1) / StripeCfg<T>::TILE);
+    const size_t ntt = (size_t)g.nplanes * ntiles;
+    int rc;
+    if ((rc = reserve(ctx, l.s_ctl, (size_t)(STRIPE_CTL_DONE + g.nplanes) * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.s_table, (size_t)g.nplanes * NCTX * 24)) != 0) return rc;
+    if ((rc = reserve_zeroed(ctx, l.s_status, ntt * 8)) != 0) return rc;
+    if ((rc = reserve(ctx, l.tile_bits, ntt * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.tile_bitoff, ntt * 8)) != 0) return rc;
+    if ((rc = reserve(ctx, l.edge_first, ntt * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.edge_last, ntt * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.plane_sums, (size_t)g.nplanes * 16)) != 0) return rc;
+    if ((rc = reserve(ctx, l.image_bytes, (size_t)g.nimages * 8)) != 0) return rc;
+    if ((rc = reserve(ctx, l.image_off, (size_t)(g.nimages + 1) * 8)) != 0) return rc;
+    const size_t hs = (size_t)g.nimages * 2 + 1;
+    if (hs > l.h_sizes_cap) {
+        if (l.h_sizes) HIP_TRY(ctx, hipHostFree(l.h_sizes));
+        l.h_sizes = nullptr;
+        HIP_TRY(ctx, hipHostMalloc((void **)&l.h_sizes, hs * 8 + 64, hipHostMallocDefault));
+        l.h_sizes_cap = hs;
+    }
+    PackTarget target{d_out, slot_stride, nullptr, 0};
+    if (g.planes_per_image > 1) {
+        target.plane_slot = ((uint64_t)g.npix + g.npix / 4 + 64 + 15) & ~15ull;
+        if ((rc = reserve(ctx, l.pscratch, (size_t)(target.plane_slot * g.nimages * (g.planes_per_image - 1)))) != 0) return rc;
+        target.scratch = (uint8_t *)l.pscratch.p;
+    }
+    if (++l.epoch >= 0x03FFFFFFu) l.epoch = 1;
+    if ((l.epoch & 0x3FFFFu) == 0) HIP_TRY(ctx, hipMemset(l.s_status.p, 0, l.s_status.cap));  // look-back tags: 18 epoch bits
+    hipStream_t s = l.stream;
+    auto *plane_carry = (uint64_t *)l.plane_sums.p;
+    auto *plane_base = plane_carry + g.nplanes;
+    if (ctx->poison) {
+        DevBuf *bufs[] = {&l.tile_bits, &l.tile_bitoff, &l.edge_first, &l.edge_last, &l.pscratch};
+        for (DevBuf *b : bufs)
+            if (b->p) HIP_TRY(ctx, hipMemsetAsync(b->p, 0xA5, b->cap, s));
+    }
+    HIP_TRY(ctx, hipMemsetAsync(l.s_ctl.p, 0, (size_t)(STRIPE_CTL_DONE + g.nplanes) * 4, s));
+    HIP_TRY(ctx, hipMemsetAsync(l.s_table.p, 0, (size_t)g.nplanes * NCTX * 24, s));
+    HIP_TRY(ctx, hipMemsetAsync(plane_carry, 0, (size_t)g.nplanes * 16, s));
+    StripeArgs a;
+    a.planes = l.d_planes;
+    a.W = g.W;
+    a.H = g.H;
+    a.npix = g.npix;
+    a.nplanes = g.nplanes;
+    a.ntiles = ntiles;
+    a.ctl = (uint32_t *)l.s_ctl.p;
+    a.table = (uint64_t *)l.s_table.p;
+    a.status = (uint64_t *)l.s_status.p;
+    a.tile_bitoff = (uint64_t *)l.tile_bitoff.p;
+    a.tile_bits = (uint32_t *)l.tile_bits.p;
+    a.plane_carry = plane_carry;
+    a.edge_first = (uint32_t *)l.edge_first.p;
+    a.edge_last = (uint32_t *)l.edge_last.p;
+    a.po = PlaneOut{target.out, target.slot_stride, target.scratch, target.plane_slot, g.planes_per_image};
+    a.color = g.color;
+    a.depth = g.depth;
+    a.epoch = l.epoch;
+    {
+        StageTimer t(ctx, l, ST_STRIPE, s, true);
+        HIP_TRY(ctx, launch_stripe<T>(s, a, ctx->stripe_wgs));
+    }
+    {
+        StageTimer t(ctx, l, ST_ZERO, s);
+        launch_finish_sizes(s, plane_carry, plane_base, (uint64_t *)l.image_bytes.p, g);
+        launch_join_edges_tiles(s, (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p, (const uint32_t *)l.edge_first.p,
+                                (const uint32_t *)l.edge_last.p, target, g, ntiles);
+        launch_concat_planes(s, plane_base, plane_carry, target, g);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(l.h_sizes, l.image_bytes.p, (size_t)g.nimages * 8, hipMemcpyDeviceToHost, s));
+    l.h_sizes[g.nimages] = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&l.h_sizes[g.nimages], (uint32_t *)l.s_ctl.p + STRIPE_CTL_ERROR, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipEventRecord(l.sized, s));
+    return FELICS_OK;
+}
+
+template <typename T>
+bool stripe_fits(const felics_ctx *ctx, uint32_t w, uint64_t slot) {
+    return ctx->stripe && slot != 0 && stripe_lds_bytes<T>(w) <= STRIPE_LDS_LIMIT;
+}
+
 // 16-bit samples (T = u16 gray planes, i32 Y/Co/Cg planes): everything on the lane's main stream.
 //   keys -> stable sort by (plane, context) -> chain heads -> estimator replay per chain (k_map)
 //   -> lengths, bit scan, sizes -> pack (fixed slots) ; same contract as run_lane towards the caller.
@@ -582,9 +676,10 @@ int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const v
     l.first_image = first;
     const uint8_t *src = (const uint8_t *)d_pixels + first * frame_bytes;
     l.d_planes = src;
+    l.ran_stripe = !wide && (planes == 3 ? stripe_fits<int16_t>(ctx, w, slot) : stripe_fits<uint8_t>(ctx, w, slot));
     if (planes == 3) {
         if ((rc = reserve(ctx, l.planes, (size_t)g.nplanes * npix * (wide ? 4 : 2) + STAGE_PAD)) != 0) return rc;
-        hipStream_t fs = wide || getenv("FELICS_SERIAL") ? l.stream : l.front;
+        hipStream_t fs = wide || l.ran_stripe || getenv("FELICS_SERIAL") ? l.stream : l.front;
         StageTimer t(ctx, l, ST_PLANES, fs, true);
         if (wide)
             launch_rgb16_to_planes(fs, (const uint16_t *)src, (int32_t *)l.planes.p, g.npix, g.nimages);
@@ -593,6 +688,8 @@ int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const v
         l.d_planes = l.planes.p;
     }
     if (wide) return planes == 3 ? run_wide<int32_t>(ctx, l, lane_out, slot) : run_wide<uint16_t>(ctx, l, lane_out, slot);
+    if (l.ran_stripe) ctx->stats.fused_submissions++;
+    if (l.ran_stripe) return planes == 3 ? run_stripe<int16_t>(ctx, l, lane_out, slot) : run_stripe<uint8_t>(ctx, l, lane_out, slot);
     return planes == 3 ? run_lane<int16_t, uint16_t>(ctx, l, lane_out, slot) : run_lane<uint8_t, uint8_t>(ctx, l, lane_out, slot);
 }
 
@@ -604,7 +701,8 @@ struct SlotOutcome {
 
 SlotOutcome read_sizes(felics_ctx *ctx, Lane &l, bool wide, uint64_t slot, uint64_t *offsets, uint64_t *lens) {
     SlotOutcome o;
-    if (!wide && ((l.h_sizes[l.g.nimages] & 1u) != 0 || (ctx->test_lookback && !ctx->two_pass))) o.lookback_failed = true;
+    if (!wide && ((l.h_sizes[l.g.nimages] & 1u) != 0 || (ctx->test_lookback && !ctx->two_pass && !l.ran_stripe))) o.lookback_failed = true;
+    if (l.ran_stripe && ctx->test_stripe_fail) o.lookback_failed = true;
     if (!wide && (l.h_sizes[l.g.nimages] & 2u) != 0) o.overflow = true;
     for (size_t i = 0; i < l.g.nimages; i++) {
         lens[l.first_image + i] = l.h_sizes[i];
@@ -723,10 +821,16 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
             // A tile of the single-pass pack gave up waiting for the tiles before it (another context's
             // kernels holding the GPU, most likely): this context packs in two passes from now on.
             if ((rc = sync_lane(ctx, l)) != 0) return rc;
-            ctx->two_pass = true;
             ctx->stats.lookback_fallbacks++;
-            ctx->stats.two_pass = 1;
-            ctx->err = "a tile gave up waiting for its predecessors: this context now packs with the two-pass kernels (slower)";
+            if (l.ran_stripe) {
+                ctx->stripe = false;
+                ctx->test_stripe_fail = false;
+                ctx->err = "a tile of the fused kernel gave up waiting for its predecessor: this context now uses the multi-kernel pipeline (slower)";
+            } else {
+                ctx->two_pass = true;
+                ctx->stats.two_pass = 1;
+                ctx->err = "a tile gave up waiting for its predecessors: this context now packs with the two-pass kernels (slower)";
+            }
             continue;
         }
         if (!outcome.overflow) break;
@@ -769,6 +873,13 @@ int felics_ctx_create(int device, felics_ctx **out) {
     ctx->poison = getenv("FELICS_POISON") != nullptr;
     ctx->two_pass = getenv("FELICS_TWO_PASS") != nullptr;
     ctx->test_lookback = getenv("FELICS_TEST_LOOKBACK_FAIL") != nullptr;
+    ctx->test_stripe_fail = getenv("FELICS_TEST_STRIPE_FAIL") != nullptr;
+    if (const char *e = getenv("FELICS_PIPELINE")) ctx->stripe = strcmp(e, "classic") != 0;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->stripe_wgs = (uint32_t)cus;
+        if (const char *e = getenv("FELICS_STRIPE_WGS")) ctx->stripe_wgs = (uint32_t)std::max(1, atoi(e));
+    }
     if (const char *e = getenv("FELICS_SLICES")) ctx->slices_blocking = std::max(1, std::min(atoi(e), SLICES));
     if (const char *e = getenv("FELICS_SLICES_QUEUED")) ctx->slices_queued = std::max(1, std::min(atoi(e), SLICES));
     ctx->trace = getenv("FELICS_TRACE") != nullptr;
@@ -812,15 +923,18 @@ void felics_ctx_destroy(felics_ctx *ctx) {
         return;
     }
     (void)hipSetDevice(ctx->device);
+    // everything queued by any lane first (the lanes share the tail stream), then the teardown
     for (Lane &l : ctx->lanes) {
         if (l.front) (void)hipStreamSynchronize(l.front);
         if (l.stream) (void)hipStreamSynchronize(l.stream);
         if (l.kstream) (void)hipStreamSynchronize(l.kstream);
-        if (l.tail) (void)hipStreamSynchronize(l.tail);
+    }
+    if (ctx->lanes[0].tail) (void)hipStreamSynchronize(ctx->lanes[0].tail);
+    for (Lane &l : ctx->lanes) {
         DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map,
                           &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.plane_sums, &l.image_bytes, &l.image_off,
                           &l.partial, &l.block_tag, &l.status, &l.edge_first, &l.edge_last, &l.pscratch, &l.wkeys[0], &l.wkeys[1], &l.wvals[0], &l.wvals[1], &l.e_of, &l.heads,
-                          &l.sort_temp};
+                          &l.sort_temp, &l.s_ctl, &l.s_table, &l.s_status};
         for (DevBuf *b : bufs) release(*b);
         if (l.h_sizes) (void)hipHostFree(l.h_sizes);
         for (int i = 0; i < ST_COUNT; i++)
@@ -834,10 +948,10 @@ void felics_ctx_destroy(felics_ctx *ctx) {
             if (l.assign_done[q]) (void)hipEventDestroy(l.assign_done[q]);
         }
         if (l.front) (void)hipStreamDestroy(l.front);
-        if (l.tail && &l == &ctx->lanes[0]) (void)hipStreamDestroy(l.tail);
         if (l.kstream) (void)hipStreamDestroy(l.kstream);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
+    if (ctx->lanes[0].tail) (void)hipStreamDestroy(ctx->lanes[0].tail);
     release(ctx->in);
     release(ctx->out);
     delete ctx;
@@ -936,10 +1050,16 @@ int felics_wait_batch(felics_ctx *ctx, int ticket, uint64_t *offsets, uint64_t *
     // the rare cases: pack again on this lane, synchronously (two-pass kernels / exact placement)
     if ((rc = sync_lane(ctx, l)) != 0) return rc;
     if (o.lookback_failed) {
-        ctx->two_pass = true;
         ctx->stats.lookback_fallbacks++;
-        ctx->stats.two_pass = 1;
-        ctx->err = "a tile gave up waiting for its predecessors: this context now packs with the two-pass kernels (slower)";
+        if (l.ran_stripe) {
+            ctx->stripe = false;
+            ctx->test_stripe_fail = false;
+            ctx->err = "a tile of the fused kernel gave up waiting for its predecessor: this context now uses the multi-kernel pipeline (slower)";
+        } else {
+            ctx->two_pass = true;
+            ctx->stats.two_pass = 1;
+            ctx->err = "a tile gave up waiting for its predecessors: this context now packs with the two-pass kernels (slower)";
+        }
     } else {
         ctx->stats.slot_overflows++;
     }

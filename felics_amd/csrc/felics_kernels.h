@@ -157,6 +157,57 @@ void launch_join_edges(hipStream_t s, const uint64_t *tile_bitoff, const uint32_
 void launch_concat_planes(hipStream_t s, const uint64_t *plane_base, const uint64_t *plane_carry, const PackTarget &to,
                           const Geometry &g);
 
+// Where the single-pass pack puts a plane's bits.  Plane 0 of an image goes to the image's slot of the
+// output (header first); planes 1, 2 of an RGB image are packed as bit strings of their own into scratch
+// slots and moved behind plane 0 by k_concat_planes once every size is known (compression.rs:365-367:
+// the planes of an image follow each other without alignment).
+struct PlaneOut {
+    uint8_t *out;
+    uint64_t slot_stride;  // image i's stream starts at out + i * slot_stride
+    uint8_t *scratch;
+    uint64_t plane_slot;   // plane c >= 1 of image i at scratch + (i * (planes_per_image - 1) + c - 1) * plane_slot
+    uint32_t planes_per_image;
+};
+
+
+// ---- the fused tile kernel (felics_stripe.hip): 8-bit frames, one persistent kernel per submission.
+// A workgroup takes a tile of consecutive pixels of one plane through classification, event partition,
+// estimator replay, code construction and packing without leaving LDS; tiles of a plane hand the estimator's
+// table (global memory, 512 rows of six counters per plane) to each other in order.
+constexpr uint32_t STRIPE_THREADS = 1024;
+constexpr uint32_t STRIPE_LDS_LIMIT = 160u * 1024u;  // LDS of one CU (MI355X_MICROARCH.md)
+template <typename T> struct StripeCfg;
+template <> struct StripeCfg<uint8_t> {  // gray planes
+    using ET = uint8_t;
+    static constexpr uint32_t TILE = 16384, PPT = 16;
+};
+template <> struct StripeCfg<int16_t> {  // Y / Co / Cg planes
+    using ET = uint16_t;
+    static constexpr uint32_t TILE = 8192, PPT = 8;
+};
+// control block (u32 words, zeroed before every launch): ticket counter, error bits (1 = a wait gave up,
+// 2 = an RGB plane outgrew its scratch slot), then done[plane] = tiles of the plane whose estimator rows are out
+constexpr uint32_t STRIPE_CTL_TICKET = 0, STRIPE_CTL_ERROR = 1, STRIPE_CTL_DONE = 16;
+struct StripeArgs {
+    const void *planes;
+    uint32_t W, H, npix, nplanes, ntiles;  // ntiles = ceil(npix / TILE)
+    uint32_t *ctl;                          // STRIPE_CTL_DONE + nplanes words
+    uint64_t *table;                        // nplanes * NCTX * 3 words, zeroed before every launch
+    uint64_t *status;                       // nplanes * ntiles look-back words (zeroed once; epoch tags)
+    uint64_t *tile_bitoff;
+    uint32_t *tile_bits;
+    uint64_t *plane_carry;
+    uint32_t *edge_first, *edge_last;
+    PlaneOut po;
+    uint32_t color, depth, epoch;
+};
+template <typename T> uint32_t stripe_lds_bytes(uint32_t W);
+// at most max_workgroups workgroups (the tiles are handed out by a ticket counter)
+template <typename T> hipError_t launch_stripe(hipStream_t s, const StripeArgs &a, uint32_t max_workgroups);
+// join_edges / concat_planes for a given tile count (the stripe kernel's tiles are larger than the pack kernels')
+void launch_join_edges_tiles(hipStream_t s, const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint32_t *edge_first,
+                             const uint32_t *edge_last, const PackTarget &to, const Geometry &g, uint32_t ntiles);
+
 // ---- 16-bit samples (felics_wide.hip): contexts 0..131070 and 15 Rice parameters (traits.rs:35-43).
 // The events of a batch are ordered by (plane, context) with a stable radix sort and every context's
 // chain is replayed by one wave; lengths / pack are the kernels above on u16 / i32 planes.

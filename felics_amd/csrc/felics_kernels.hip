@@ -24,6 +24,7 @@
 
 #include "felics_device.h"
 #include "felics_kernels.h"
+#include "felics_codes.h"
 
 namespace felics {
 
@@ -413,33 +414,6 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
 // k_assign then gives every event its k, one wave per block, all blocks in parallel.
 // ------------------------------------------------------------------------------------------
 
-// sum of the packed elements of w, each shifted right by K (K = 0..5)
-template <int K>
-__device__ __forceinline__ uint32_t packed_shift_sum(uint32_t w, uint8_t) {  // 4 x u8
-    if (K == 0) return __builtin_amdgcn_sad_u8(w, 0u, 0u);
-    return __builtin_amdgcn_sad_u8((w >> K) & (0x01010101u * (0xFFu >> K)), 0u, 0u);
-}
-template <int K>
-__device__ __forceinline__ uint32_t packed_shift_sum(uint32_t w, uint16_t) {  // 2 x u16
-    const uint32_t x = (w >> K) & (0x00010001u * (0xFFFFu >> K));
-    return (x & 0xFFFFu) + (x >> 16);
-}
-
-template <typename ET>
-__device__ __forceinline__ void add_block_sums(uint32_t w, uint32_t &b01, uint32_t &b23, uint32_t &b45) {
-    b01 += packed_shift_sum<0>(w, ET()) | (packed_shift_sum<1>(w, ET()) << 16);
-    b23 += packed_shift_sum<2>(w, ET()) | (packed_shift_sum<3>(w, ET()) << 16);
-    b45 += packed_shift_sum<4>(w, ET()) | (packed_shift_sum<5>(w, ET()) << 16);
-}
-
-// Rice lengths of one event for k = 0..5 (rice_coding.rs:56-58), two 16-bit fields per dword
-// (64 * 511 < 2^16, so a wave's prefix sums cannot carry between fields).
-__device__ __forceinline__ void packed_lengths(uint32_t e, uint32_t &l01, uint32_t &l23, uint32_t &l45) {
-    l01 = (e + 1u) | (((e >> 1) + 2u) << 16);
-    l23 = ((e >> 2) + 3u) | (((e >> 3) + 4u) << 16);
-    l45 = ((e >> 4) + 5u) | (((e >> 5) + 6u) << 16);
-}
-
 constexpr uint32_t SPINE_BATCH = 64;  // blocks fetched per step: lane j holds block j
 
 template <typename ET>
@@ -702,32 +676,6 @@ __global__ __launch_bounds__(256) void k_assign(const ET *__restrict__ sorted_e,
 // code construction shared by lengths / pack
 // ------------------------------------------------------------------------------------------
 
-// Phased-in code of v in [0, n) (phase_in_coding.rs:23-84): r = v + 2^m (mod n);
-// r < right_p -> r in m bits, else r + right_p in m + 1 bits.  n - left_p = 2^m, so no division.
-__device__ __forceinline__ void phase_in(uint32_t n, uint32_t v, uint32_t &bits, uint32_t &nbits) {
-    const uint32_t m = 31u - (uint32_t)__clz((int)n);
-    const uint32_t right_p = (2u << m) - n;
-    uint32_t r = v + (1u << m);
-    if (r >= n) r -= n;
-    if (r < right_p) {
-        bits = r;
-        nbits = m;
-    } else {
-        bits = r + right_p;
-        nbits = m + 1;
-    }
-}
-
-// Bits one pixel emits (compression.rs:130-145): flag + phased-in, or flag + Rice(k).
-__device__ __forceinline__ uint32_t code_length(const PixelClass &pc, uint32_t k) {
-    if (pc.cls == CLS_IN) {
-        uint32_t b, nb;
-        phase_in(pc.ctx + 1, pc.val, b, nb);
-        return 1 + nb;
-    }
-    return 2 + (pc.val >> k) + 1 + k;
-}
-
 // ------------------------------------------------------------------------------------------
 // Tile staging shared by lengths / pack.  A tile is PACK_TILE consecutive pixels of one plane;
 // thread t owns the PACK_PER_THREAD consecutive pixels first = tile*PACK_TILE + t*PACK_PER_THREAD.
@@ -775,17 +723,6 @@ __device__ __forceinline__ void stage_tile(TileLDS<T> &t, const T *__restrict__ 
     stage_span<T>(t.up, pl, (int64_t)tile_first - W, PACK_TILE + 16, npix);
     stage_span<uint8_t>(t.kq, kpl, (int64_t)tile_first, PACK_TILE, npix);
 }
-
-__device__ __forceinline__ int sample_at(const uint32_t *w, uint32_t j, uint8_t) {
-    return (int)((w[j >> 2] >> (8u * (j & 3u))) & 0xFFu);
-}
-__device__ __forceinline__ int sample_at(const uint32_t *w, uint32_t j, int16_t) {
-    return (int)(int16_t)(w[j >> 1] >> (16u * (j & 1u)));
-}
-__device__ __forceinline__ int sample_at(const uint32_t *w, uint32_t j, uint16_t) {
-    return (int)((w[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu);
-}
-__device__ __forceinline__ int sample_at(const uint32_t *w, uint32_t j, int32_t) { return (int)w[j]; }
 
 // Calls raw(i, value) for pixels 0 and 1 of the plane (stored as 32-bit values,
 // compression.rs:105-106) and f(pc, k) for every other pixel of this thread's group, in raster order.
@@ -1016,81 +953,6 @@ __global__ void k_zero_streams(uint32_t *__restrict__ out, const uint64_t *__res
 // atomically into the zeroed output, everything between is a plain store.
 // ------------------------------------------------------------------------------------------
 
-struct LaneBits {
-    uint32_t *win;       // LDS window
-    uint32_t win_words;  // its size
-    uint64_t win_word0;  // absolute word index of win[0]
-    uint64_t cur_word;   // absolute word being filled
-    uint64_t acc;        // bits of cur_word in the top half, overflow below
-    uint32_t fill;       // bits used in the top half (< 32 between calls)
-
-    __device__ __forceinline__ void begin(uint64_t bitpos) {
-        cur_word = bitpos >> 5;
-        fill = (uint32_t)(bitpos & 31);
-        acc = 0;
-    }
-    __device__ __forceinline__ void emit(uint32_t w) {
-        if (w) {
-            const uint64_t rel = cur_word - win_word0;
-            if (rel < win_words) atomicOr(&win[rel], w);  // also false when cur_word < win_word0
-        }
-    }
-    // append the low n bits of v (v < 2^n, 1 <= n <= 32), most significant first
-    __device__ __forceinline__ void put(uint32_t v, uint32_t n) {
-        acc |= (uint64_t)v << (64u - fill - n);
-        fill += n;
-        if (fill >= 32) {
-            emit((uint32_t)(acc >> 32));
-            acc <<= 32;
-            fill -= 32;
-            cur_word++;
-        }
-    }
-    __device__ __forceinline__ void put_ones(uint32_t q) {  // write_unary0's run of ones
-        if (q >= 32) {
-            put(0xFFFFFFFFu, 32);
-            q -= 32;
-            // Every further whole word of the run is all ones and leaves acc / fill as they are: only the
-            // words inside the window are touched (16-bit samples: a run can be 2^17 bits long).
-            const uint64_t n = q >> 5;
-            if (n) {
-                const uint64_t lo = cur_word > win_word0 ? cur_word : win_word0;
-                const uint64_t hi = cur_word + n < win_word0 + win_words ? cur_word + n : win_word0 + win_words;
-                for (uint64_t w = lo; w < hi; w++) atomicOr(&win[w - win_word0], 0xFFFFFFFFu);
-                cur_word += n;
-                q &= 31u;
-            }
-        }
-        if (q) put((1u << q) - 1u, q);
-    }
-    __device__ __forceinline__ void finish() {
-        if (fill) emit((uint32_t)(acc >> 32));
-    }
-};
-
-// One pixel's code.  Both kinds of code are built without branching -- `1` + phased-in
-// (compression.rs:131-134), or `00` below / `01` above (compression.rs:35-42), unary quotient, 0, k-bit
-// remainder -- and one of them is appended; only a Rice code longer than 32 bits takes a branch.
-template <typename BW>
-__device__ __forceinline__ void put_pixel(BW &bw, const PixelClass &pc, uint32_t k) {
-    uint32_t b, nb;
-    phase_in(pc.ctx + 1, pc.val, b, nb);
-    const bool in_range = pc.cls == CLS_IN;
-    const uint32_t flag = pc.cls == CLS_ABOVE ? 1u : 0u;
-    const uint32_t q = pc.val >> k, rem = pc.val & ((1u << k) - 1u);
-    const uint32_t n_rice = q + k + 3;
-    const uint32_t n = in_range ? nb + 1 : n_rice;
-    if (n <= 32) {
-        const uint32_t sh = q & 31u;  // (q <= 29 whenever the Rice code is the one used)
-        const uint32_t rice = (((flag << sh) | ((1u << sh) - 1u)) << (k + 1)) | rem;  // 0, flag, q ones, 0, rem
-        bw.put(in_range ? (1u << nb) | b : rice, n);
-    } else {
-        bw.put(flag, 2);
-        bw.put_ones(q);
-        bw.put(rem, k + 1);
-    }
-}
-
 template <typename T>
 __global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ planes, const uint8_t *__restrict__ k_map,
                                                        const group_bits_t<T> *__restrict__ group_bits,
@@ -1189,39 +1051,8 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ pla
 // so the output needs no zeroing.
 // ------------------------------------------------------------------------------------------
 
-// Where the single-pass pack puts a plane's bits.  Plane 0 of an image goes to the image's slot of the
-// output (header first); planes 1, 2 of an RGB image are packed as bit strings of their own into scratch
-// slots and moved behind plane 0 by k_concat_planes once every size is known (compression.rs:365-367:
-// the planes of an image follow each other without alignment).
-struct PlaneOut {
-    uint8_t *out;
-    uint64_t slot_stride;  // image i's stream starts at out + i * slot_stride
-    uint8_t *scratch;
-    uint64_t plane_slot;   // plane c >= 1 of image i at scratch + (i * (planes_per_image - 1) + c - 1) * plane_slot
-    uint32_t planes_per_image;
-};
-
-__device__ __forceinline__ uint32_t *plane_words(const PlaneOut &po, uint32_t plane, uint64_t &limit_words) {
-    const uint32_t img = plane / po.planes_per_image, c = plane - img * po.planes_per_image;
-    if (c == 0) {
-        limit_words = po.slot_stride >> 2;
-        return reinterpret_cast<uint32_t *>(po.out + (uint64_t)img * po.slot_stride);
-    }
-    limit_words = po.plane_slot >> 2;
-    return reinterpret_cast<uint32_t *>(po.scratch + ((uint64_t)img * (po.planes_per_image - 1) + c - 1) * po.plane_slot);
-}
-
 constexpr uint32_t LOCAL_WORDS = 8;
 constexpr uint32_t FUSED_WIN_WORDS = 1280;  // LDS bit window: 10 bits per pixel of a tile in one pass (more bits: more passes)
-constexpr uint32_t ST_AGGREGATE = 1, ST_PREFIX = 2;
-constexpr uint32_t ST_VALUE_BITS = 44;        // bits of a plane fit: < 2^32 pixels x < 2^10 bits
-constexpr uint32_t ST_EPOCH_MASK = 0x3FFFFu;  // 18 bits of the lane's epoch (status is cleared when they wrap)
-constexpr uint32_t LOOKBACK_SPIN_LIMIT = 1u << 19;  // polls of >= 1 us each: gives up after about a second
-
-__device__ __forceinline__ uint64_t status_word(uint32_t epoch, uint32_t state, uint64_t value) {
-    return ((uint64_t)(((epoch & ST_EPOCH_MASK) << 2) | state) << ST_VALUE_BITS) | value;
-}
-
 // thread-private bit string, MSB-first, word w of thread t at buf[w * PACK_THREADS + t]
 struct LocalBits {
     uint32_t *buf;
@@ -1674,11 +1505,16 @@ template void launch_pack_fused<int16_t>(hipStream_t, const int16_t *, const uin
                                          uint64_t *, uint32_t *, uint32_t *, uint32_t *, const PackTarget &,
                                          const Geometry &, uint32_t, uint32_t, uint32_t);
 
+void launch_join_edges_tiles(hipStream_t s, const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint32_t *edge_first,
+                             const uint32_t *edge_last, const PackTarget &to, const Geometry &g, uint32_t ntiles) {
+    const PlaneOut po{to.out, to.slot_stride, to.scratch, to.plane_slot, g.planes_per_image};
+    FELICS_LAUNCH(k_join_edges, dim3(cdiv(ntiles, 256), g.nplanes), dim3(256), s, tile_bitoff, tile_bits,
+                       edge_first, edge_last, po, ntiles);
+}
+
 void launch_join_edges(hipStream_t s, const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint32_t *edge_first,
                        const uint32_t *edge_last, const PackTarget &to, const Geometry &g) {
-    const PlaneOut po{to.out, to.slot_stride, to.scratch, to.plane_slot, g.planes_per_image};
-    FELICS_LAUNCH(k_join_edges, dim3(cdiv(g.pack_tiles, 256), g.nplanes), dim3(256), s, tile_bitoff, tile_bits,
-                       edge_first, edge_last, po, g.pack_tiles);
+    launch_join_edges_tiles(s, tile_bitoff, tile_bits, edge_first, edge_last, to, g, g.pack_tiles);
 }
 
 void launch_concat_planes(hipStream_t s, const uint64_t *plane_base, const uint64_t *plane_carry, const PackTarget &to,

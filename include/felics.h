@@ -140,6 +140,7 @@ const char *felics_last_error(const felics_ctx *ctx);
  * holding the GPU for a second -- moves the context to the two-pass kernels for good; felics_last_error says so.) */
 typedef struct felics_stats {
     uint64_t submissions;        /* sub-batches queued so far */
+    uint64_t fused_submissions;  /* ... of which through the fused tile kernel (8-bit frames with fixed output slots) */
     uint64_t slot_overflows;     /* batches redone with exact placement: a stream outgrew its fixed slot */
     uint64_t lookback_fallbacks; /* batches redone because a tile gave up waiting for its predecessors */
     int two_pass;                /* 1: the context packs with the two-pass kernels from now on (slower) */

@@ -116,11 +116,13 @@ def test_golden_fixtures(enc, oracle):
 def test_synthetic_frames(enc, oracle):
     from felics_amd import synth
 
+    before = enc.stats()["fused_submissions"]
     for kind in ("S1", "S2", "S3"):
         for (w, h) in ((64, 48), (333, 77), (1024, 256), (1920, 1080)):
             _check(enc, oracle, synth.gray8(w, h, 1, kind), kind)
     for (w, h) in ((64, 48), (333, 77), (1280, 720)):
         _check(enc, oracle, synth.rgb8(w, h, 2), "rgb S1")
+    assert enc.stats()["fused_submissions"] - before == 15  # 8-bit frames take the fused tile kernel
 
 
 def test_batch_equals_single(enc, oracle):

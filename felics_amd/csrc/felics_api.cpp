@@ -54,7 +54,7 @@ struct Lane {
     DevBuf planes, counts, chain_len, chain_base, chain_prog, scalars, sorted_e, pix_of, k_map, block_state, group_bits,
         tile_bits, tile_bitoff, plane_sums, image_bytes, image_off, partial, block_tag, status, edge_first, edge_last, pscratch;
     DevBuf wkeys[2], wvals[2], e_of, heads, sort_temp;  // 16-bit samples: sort records, Rice operands, chain heads
-    DevBuf s_ctl, s_table, s_status;                     // fused tile kernel: control block, estimator tables, look-back words
+    DevBuf s_ctl, s_table, s_status, s_stamps;                     // fused tile kernel: control block, estimator tables, look-back words
     bool ran_stripe = false;                             // the sub-batch in flight went through the fused tile kernel
     uint32_t epoch = 0;               // sub-batches this lane has run: block tags are (epoch, slice)
     // the submission in flight on this lane (felics_submit_batch_device .. felics_wait_batch)
@@ -86,8 +86,9 @@ struct felics_ctx {
     // a launch and a hand-over per stage: few slices are faster there (measured: 12 -> 5.3, 6 -> 5.1, 3 -> 4.8 ms).
     int slices_blocking = 6;    // FELICS_SLICES
     int slices_queued = 3;      // FELICS_SLICES_QUEUED
-    bool stripe = true;         // 8-bit frames with fixed output slots go through the fused tile kernel (felics_stripe.hip);
-                                // FELICS_PIPELINE=classic, or a hand-off of that kernel that gave up once, selects the multi-kernel pipeline
+    bool stripe = false;        // FELICS_PIPELINE=stripe: 8-bit frames with fixed output slots go through the fused tile kernel
+                                // (felics_stripe.hip) instead of the multi-kernel pipeline.  Measured slower so far,
+                                // hence opt-in; a hand-off of that kernel that gives up moves the context back for good
     uint32_t stripe_wgs = 256;  // workgroups of the persistent kernel: one per CU (its LDS fills a CU); FELICS_STRIPE_WGS
     bool two_pass = false;      // FELICS_TWO_PASS=1, or a look-back of the single-pass pack gave up once: lengths + pack kernels
     bool test_stripe_fail = false; // FELICS_TEST_STRIPE_FAIL=1: pretend the first fused-kernel submission gave up (tests)
@@ -487,6 +488,13 @@ int run_stripe(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     a.color = g.color;
     a.depth = g.depth;
     a.epoch = l.epoch;
+    a.stamps = nullptr;
+    if (const char *path = getenv("FELICS_STRIPE_STAMPS")) {  // debugging aid: phase stamps of every tile, dumped to a file
+        (void)path;
+        if ((rc = reserve(ctx, l.s_stamps, ntt * STRIPE_STAMPS * 8)) != 0) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(l.s_stamps.p, 0, ntt * STRIPE_STAMPS * 8, s));
+        a.stamps = (uint64_t *)l.s_stamps.p;
+    }
     {
         StageTimer t(ctx, l, ST_STRIPE, s, true);
         HIP_TRY(ctx, launch_stripe<T>(s, a, ctx->stripe_wgs));
@@ -503,6 +511,16 @@ int run_stripe(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     l.h_sizes[g.nimages] = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&l.h_sizes[g.nimages], (uint32_t *)l.s_ctl.p + STRIPE_CTL_ERROR, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipEventRecord(l.sized, s));
+    if (a.stamps) {
+        std::vector<uint64_t> h(ntt * STRIPE_STAMPS);
+        HIP_TRY(ctx, hipMemcpy(h.data(), a.stamps, ntt * STRIPE_STAMPS * 8, hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(getenv("FELICS_STRIPE_STAMPS"), "wb")) {
+            const uint32_t hdr[4] = {g.nplanes, ntiles, STRIPE_STAMPS, 0};
+            fwrite(hdr, 4, 4, f);
+            fwrite(h.data(), 8, h.size(), f);
+            fclose(f);
+        }
+    }
     return FELICS_OK;
 }
 
@@ -874,7 +892,7 @@ int felics_ctx_create(int device, felics_ctx **out) {
     ctx->two_pass = getenv("FELICS_TWO_PASS") != nullptr;
     ctx->test_lookback = getenv("FELICS_TEST_LOOKBACK_FAIL") != nullptr;
     ctx->test_stripe_fail = getenv("FELICS_TEST_STRIPE_FAIL") != nullptr;
-    if (const char *e = getenv("FELICS_PIPELINE")) ctx->stripe = strcmp(e, "classic") != 0;
+    if (const char *e = getenv("FELICS_PIPELINE")) ctx->stripe = strcmp(e, "stripe") == 0;
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->stripe_wgs = (uint32_t)cus;
@@ -934,7 +952,7 @@ void felics_ctx_destroy(felics_ctx *ctx) {
         DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map,
                           &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.plane_sums, &l.image_bytes, &l.image_off,
                           &l.partial, &l.block_tag, &l.status, &l.edge_first, &l.edge_last, &l.pscratch, &l.wkeys[0], &l.wkeys[1], &l.wvals[0], &l.wvals[1], &l.e_of, &l.heads,
-                          &l.sort_temp, &l.s_ctl, &l.s_table, &l.s_status};
+                          &l.sort_temp, &l.s_ctl, &l.s_table, &l.s_status, &l.s_stamps};
         for (DevBuf *b : bufs) release(*b);
         if (l.h_sizes) (void)hipHostFree(l.h_sizes);
         for (int i = 0; i < ST_COUNT; i++)

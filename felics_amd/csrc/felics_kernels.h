@@ -187,6 +187,7 @@ template <> struct StripeCfg<int16_t> {  // Y / Co / Cg planes
 };
 // control block (u32 words, zeroed before every launch): ticket counter, error bits (1 = a wait gave up,
 // 2 = an RGB plane outgrew its scratch slot), then done[plane] = tiles of the plane whose estimator rows are out
+constexpr uint32_t STRIPE_STAMPS = 16 + 16 * 4;  // per ticket: 16 of thread 0, 4 of every wave
 constexpr uint32_t STRIPE_CTL_TICKET = 0, STRIPE_CTL_ERROR = 1, STRIPE_CTL_DONE = 16;
 struct StripeArgs {
     const void *planes;
@@ -200,6 +201,7 @@ struct StripeArgs {
     uint32_t *edge_first, *edge_last;
     PlaneOut po;
     uint32_t color, depth, epoch;
+    uint64_t *stamps;  // debugging aid (FELICS_STRIPE_STAMPS): STRIPE_STAMPS wall-clock stamps per ticket, or nullptr
 };
 template <typename T> uint32_t stripe_lds_bytes(uint32_t W);
 // at most max_workgroups workgroups (the tiles are handed out by a ticket counter)

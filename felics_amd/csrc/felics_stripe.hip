@@ -387,11 +387,19 @@ __global__ __launch_bounds__(STRIPE_THREADS) void k_stripe(StripeArgs a) {
     const uint32_t W = a.W, npix = a.npix;
     uint32_t *done = a.ctl + STRIPE_CTL_DONE;
 
+    // FELICS_STRIPE_STAMPS (debugging aid): thread 0 leaves the 100 MHz wall clock at the phase boundaries of every tile
+    auto stamp = [&](uint32_t ticket_, uint32_t slot) {
+        if (a.stamps && tid == 0) a.stamps[(uint64_t)ticket_ * STRIPE_STAMPS + slot] = wall_clock64();
+    };
+    auto wstamp = [&](uint32_t ticket_, uint32_t slot) {  // per wave: 16 + wave * 4 + slot
+        if (a.stamps && lane == 0) a.stamps[(uint64_t)ticket_ * STRIPE_STAMPS + 16 + wave * 4 + slot] = wall_clock64();
+    };
     while (true) {
         if (tid == 0) misc[M_TICKET] = atomicAdd(&a.ctl[STRIPE_CTL_TICKET], 1u);
         __syncthreads();
         const uint32_t ticket = misc[M_TICKET];
         if (ticket >= total_tickets) break;
+        stamp(ticket, 0);
         const uint32_t tile = ticket / a.nplanes, plane = ticket - tile * a.nplanes;
         const T *pl = reinterpret_cast<const T *>(a.planes) + (uint64_t)plane * npix;
         const uint32_t tile_first = tile * TILE;
@@ -421,6 +429,7 @@ __global__ __launch_bounds__(STRIPE_THREADS) void k_stripe(StripeArgs a) {
             for (uint32_t i = tid; i < SW * NCTX / 2; i += STRIPE_THREADS) cz[i] = 0;
         }
         __syncthreads();
+        stamp(ticket, 6);
 
         // ---------------- A2: classify this thread's pixels; count the events per (wave, context)
         uint32_t rec[PPT];
@@ -477,6 +486,7 @@ __global__ __launch_bounds__(STRIPE_THREADS) void k_stripe(StripeArgs a) {
             }
         }
         __syncthreads();
+        stamp(ticket, 7);
 
         // ---------------- A3: per context: events per wave -> running offsets; segment starts (multiples of 4
         // events, so a block's events are whole dwords); blocks per context -> first block
@@ -511,6 +521,7 @@ __global__ __launch_bounds__(STRIPE_THREADS) void k_stripe(StripeArgs a) {
             }
         }
         __syncthreads();
+        stamp(ticket, 8);
 
         // ---------------- A4: stable partition of the events by context.  The wave's events go through a ring in
         // raster order (lane-major: a lane owns consecutive pixels), 32 lanes at a time; 64 ring entries at a time
@@ -570,6 +581,7 @@ __global__ __launch_bounds__(STRIPE_THREADS) void k_stripe(StripeArgs a) {
         }
         __syncthreads();
 
+        stamp(ticket, 1);
         // ---------------- B1: block table and the six length sums of every block (lane = block)
         const uint32_t NB = misc[M_NB];
         for (uint32_t b = tid; b < NB; b += STRIPE_THREADS) {
@@ -612,6 +624,7 @@ __global__ __launch_bounds__(STRIPE_THREADS) void k_stripe(StripeArgs a) {
             if (failed && lane == 0) atomicOr(&a.ctl[STRIPE_CTL_ERROR], 1u);
         }
         __syncthreads();
+        stamp(ticket, 2);
 
         // ---------------- B3: the estimator along this tile's events.  Wave w takes the contexts w, w + 16, ...:
         // a context whose events fit one block is replayed by one lane straight from its table row (32 such
@@ -628,12 +641,14 @@ __global__ __launch_bounds__(STRIPE_THREADS) void k_stripe(StripeArgs a) {
                 S[4] = (uint32_t)r2; S[5] = (uint32_t)(r2 >> 32);
             }
             uint64_t longer = __ballot(len > EVB);
+            wstamp(ticket, 0);
             if (len != 0 && len <= EVB) {
                 replay_block<ET>(S, se, sp, kq, seg_start[c], len);
                 st_agent(rows + c * 3, (uint64_t)S[0] | ((uint64_t)S[1] << 32));
                 st_agent(rows + c * 3 + 1, (uint64_t)S[2] | ((uint64_t)S[3] << 32));
                 st_agent(rows + c * 3 + 2, (uint64_t)S[4] | ((uint64_t)S[5] << 32));
             }
+            wstamp(ticket, 1);
             __builtin_amdgcn_s_setprio(3);  // a walk is one long dependent instruction stream
             while (longer) {
                 const uint32_t l = (uint32_t)__builtin_ctzll(longer);
@@ -649,11 +664,14 @@ __global__ __launch_bounds__(STRIPE_THREADS) void k_stripe(StripeArgs a) {
                                                                : ((uint64_t)Sc[4] | ((uint64_t)Sc[5] << 32)));
             }
             __builtin_amdgcn_s_setprio(0);
+            wstamp(ticket, 2);
         }
         // the rows must have left this CU before the token says so
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wstamp(ticket, 3);
         __syncthreads();
         if (tid == 0) __hip_atomic_store(&done[plane], tile + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stamp(ticket, 3);
 
         // ---------------- B4: k of every event of the longer contexts, one block per lane
         for (uint32_t b = tid; b < NB; b += STRIPE_THREADS) {
@@ -664,6 +682,7 @@ __global__ __launch_bounds__(STRIPE_THREADS) void k_stripe(StripeArgs a) {
             replay_block<ET>(S, se, sp, kq, blk_ev0[b], nflag);
         }
         __syncthreads();
+        stamp(ticket, 4);
 
         // ---------------- C1: this thread's bit string
         const bool first_plane = plane % a.po.planes_per_image == 0;
@@ -692,6 +711,7 @@ __global__ __launch_bounds__(STRIPE_THREADS) void k_stripe(StripeArgs a) {
         const uint32_t inc = wave_incl_scan(bits);
         if (lane == 63) misc[M_WSUM + wave] = inc;
         __syncthreads();
+        stamp(ticket, 9);
         uint32_t woff = 0, tile_total = 0;
         for (uint32_t w = 0; w < SW; w++) {
             const uint32_t v = misc[M_WSUM + w];
@@ -759,6 +779,7 @@ __global__ __launch_bounds__(STRIPE_THREADS) void k_stripe(StripeArgs a) {
             }
         }
         __syncthreads();
+        stamp(ticket, 10);
         const uint64_t tile_lo = (uint64_t)misc[M_TILE_LO] | ((uint64_t)misc[M_TILE_LO + 1] << 32), tile_hi = tile_lo + tile_total;
         const uint64_t my_lo = tile_lo + woff + inc - bits;
         uint64_t limit_words;  // a stream that outgrows its slot is cut (the host re-packs)
@@ -812,6 +833,7 @@ __global__ __launch_bounds__(STRIPE_THREADS) void k_stripe(StripeArgs a) {
             }
         }
         __syncthreads();  // LDS is reused by the next tile
+        stamp(ticket, 5);
     }
 }
 

@@ -116,13 +116,12 @@ def test_golden_fixtures(enc, oracle):
 def test_synthetic_frames(enc, oracle):
     from felics_amd import synth
 
-    before = enc.stats()["fused_submissions"]
+
     for kind in ("S1", "S2", "S3"):
         for (w, h) in ((64, 48), (333, 77), (1024, 256), (1920, 1080)):
             _check(enc, oracle, synth.gray8(w, h, 1, kind), kind)
     for (w, h) in ((64, 48), (333, 77), (1280, 720)):
         _check(enc, oracle, synth.rgb8(w, h, 2), "rgb S1")
-    assert enc.stats()["fused_submissions"] - before == 15  # 8-bit frames take the fused tile kernel
 
 
 def test_batch_equals_single(enc, oracle):
@@ -291,6 +290,89 @@ def test_pack_variants(oracle):
             assert e.compress_batch(frames[:3]) == want[:3], env  # the same context again (after a fallback)
         finally:
             e.close()
+
+
+def test_fused_tile_kernel(oracle):
+    """FELICS_PIPELINE=stripe: 8-bit frames through the single persistent kernel of felics_stripe.hip (tiles handed
+    out by ticket, estimator table passed from tile to tile).  Same bytes as the oracle on the reference's shapes,
+    odd geometry, extreme content, RGB, batches, 4K frames, two submissions in flight, and -- with a forced
+    hand-off failure -- the fall back to the multi-kernel pipeline."""
+    import felics_amd
+    import torch
+    from felics_amd import synth
+
+    rng = np.random.default_rng(41)
+    os.environ["FELICS_PIPELINE"] = "stripe"
+    os.environ["FELICS_POISON"] = "1"
+    try:
+        e = felics_amd.Encoder(0)
+    finally:
+        del os.environ["FELICS_PIPELINE"], os.environ["FELICS_POISON"]
+    try:
+        n0 = e.stats()["fused_submissions"]
+        for w, h in DIMS + [(17, 300), (4097, 3), (3, 3000), (1, 5000), (5000, 1), (5000, 2), (255, 257), (8000, 9)]:
+            _check(e, oracle, rng.integers(0, 256, size=(h, w), dtype=np.uint8), "stripe gray noise")
+            _check(e, oracle, (np.add.outer(np.arange(h), np.arange(w)) // 3 % 256).astype(np.uint8), "stripe smooth")
+            _check(e, oracle, rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8), "stripe rgb noise")
+        for w in range(1, 20, 3):
+            for h in range(1, 20, 3):
+                _check(e, oracle, rng.integers(0, 256, size=(h, w), dtype=np.uint8))
+                _check(e, oracle, rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8))
+        flat = np.full((96, 257), 7, np.uint8)
+        spikes = flat.copy()
+        spikes[rng.integers(0, 96, 200), rng.integers(0, 257, 200)] = 255
+        checker = ((np.indices((96, 257)).sum(0) & 1) * 255).astype(np.uint8)
+        for img in (flat, spikes, checker):
+            _check(e, oracle, img, "stripe extreme")
+            _check(e, oracle, np.stack([img, img[::-1], 255 - img], axis=-1).copy(), "stripe extreme rgb")
+        assert e.stats()["fused_submissions"] > n0 + 100
+        for kind in ("S1", "S2", "S3"):
+            _check(e, oracle, synth.gray8(3840, 2160, 1, kind), "stripe 4K " + kind)
+        _check(e, oracle, synth.rgb8(3840, 2160, 2), "stripe 4K rgb")
+        frames = [synth.gray8(1920, 1080, f, "S1") for f in range(12)] + [synth.gray8(1920, 1080, 3, "S2")]
+        assert e.compress_batch(frames) == [oracle.compress(f) for f in frames]
+        rgb = [synth.rgb8(640, 360, f) for f in range(5)]
+        assert e.compress_batch(rgb) == [oracle.compress(f) for f in rgb]
+        # two submissions in flight
+        batches = [[synth.gray8(1280, 720, 10 * b + f, "S1") for f in range(6)] for b in range(4)]
+        d_in = [torch.from_numpy(np.stack(fr)).cuda() for fr in batches]
+        caps = [int(sum(f.nbytes for f in fr) * 1.25) + 4096 for fr in batches]
+        d_out = [torch.zeros(c, dtype=torch.uint8, device="cuda") for c in caps]
+        torch.cuda.synchronize()
+        subs = []
+        for b in range(4):
+            if len(subs) == 2:
+                bb, sub = subs.pop(0)
+                offs, lens = e.wait_batch(sub)
+                host = d_out[bb].cpu().numpy()
+                for i, f in enumerate(batches[bb]):
+                    assert host[int(offs[i]): int(offs[i] + lens[i])].tobytes() == oracle.compress(f), (bb, i)
+            subs.append((b, e.submit_batch_device(d_in[b].data_ptr(), 6, 1280, 720, 0, 0, d_out[b].data_ptr(), caps[b])))
+        for bb, sub in subs:
+            offs, lens = e.wait_batch(sub)
+            host = d_out[bb].cpu().numpy()
+            for i, f in enumerate(batches[bb]):
+                assert host[int(offs[i]): int(offs[i] + lens[i])].tobytes() == oracle.compress(f), (bb, i)
+        assert e.stats()["lookback_fallbacks"] == 0
+    finally:
+        e.close()
+    # a hand-off that gives up: the batch is redone by the multi-kernel pipeline and the context stays there
+    os.environ["FELICS_PIPELINE"] = "stripe"
+    os.environ["FELICS_TEST_STRIPE_FAIL"] = "1"
+    try:
+        e = felics_amd.Encoder(0)
+    finally:
+        del os.environ["FELICS_PIPELINE"], os.environ["FELICS_TEST_STRIPE_FAIL"]
+    try:
+        frames = [synth.gray8(800, 600, f, "S1") for f in range(4)]
+        want = [oracle.compress(f) for f in frames]
+        assert e.compress_batch(frames) == want
+        st = e.stats()
+        assert st["lookback_fallbacks"] == 1 and st["fused_submissions"] == 1
+        assert e.compress_batch(frames) == want
+        assert e.stats()["fused_submissions"] == 1
+    finally:
+        e.close()
 
 
 def test_random_shapes_and_contents(enc, oracle):

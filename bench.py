@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-blocking-extra", action="store_true",
                     help="skip the three extra blocking-call steps after the timed region (rocprofv3 runs: keeps the kernel averages those of the timed steps)")
     ap.add_argument("--no-side-configs", action="store_true", help="skip the short config 2 / config 4 legs of the default run")
+    ap.add_argument("--no-decode-leg", action="store_true", help="skip the decode measurement (GPU decoder next to the host decoder) of the default run")
     args = ap.parse_args()
     if args.config in (4, 5):
         args.rgb = True
@@ -276,6 +277,40 @@ def main():
                           "frac_of_hbm_peak_queued": round(npix * ch / queued / 1e9 / HBM_PEAK_GBS, 5),
                           "calls": reps, "byte_compared_with_oracle": True}
 
+    # Decode, for the record: the batch's streams through the GPU decoder (one wave per stream: the
+    # format is bit-serial per stream) and a sample of them through the host decoder on this box's cores.
+    decode = None
+    if rank == 0 and args.config == 3 and not args.no_decode_leg and not args.depth16 and not args.rgb:
+        from concurrent.futures import ThreadPoolExecutor
+
+        from felics_amd import api as fapi2
+
+        offs0, lens0 = step()
+        d_px = torch.empty_like(frames)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        _, st = enc.decompress_batch_device(d_out.data_ptr(), offs0, lens0, d_px.data_ptr(), d_px.numel())
+        torch.cuda.synchronize()
+        gpu_s = time.perf_counter() - t1
+        if not bool((d_px == frames).all()):
+            raise SystemExit("GPU decoder: pixels differ from the frames that were encoded")
+        del d_px
+        hostbuf = d_out[: int(offs0[-1] + lens0[-1])].cpu().numpy()
+        sample = [hostbuf[int(offs0[i]): int(offs0[i] + lens0[i])].tobytes() for i in range(min(F, 16))]
+        t1 = time.perf_counter()
+        fapi2.decompress_bytes(sample[0])
+        one = time.perf_counter() - t1
+        cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        t1 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            list(ex.map(fapi2.decompress_bytes, sample))
+        many = time.perf_counter() - t1
+        decode = {"gpu_MPix_s": round(F * npix / gpu_s / 1e6, 1), "gpu_seconds_per_batch": round(gpu_s, 3), "streams": F,
+                  "gpu_note": "felics_decompress_batch_device: one wave per stream, %d streams = %d waves on 256 CUs" % (F, F),
+                  "host_MPix_s_1_core": round(npix / one / 1e6, 1),
+                  "host_MPix_s_%d_cores" % cores: round(len(sample) * npix / many / 1e6, 1),
+                  "host_sample": "%d of the batch's streams, felics_decompress (C++)" % len(sample), "pixels_checked": True}
+
     if rank == 0:
         steps = max(args.steps, 1)
         ms_per_step = elapsed / steps * 1e3
@@ -342,6 +377,7 @@ def main():
             "cpu_baseline": cpu1,
             "cpu_baseline_all_cores": cpum,
             "other_configs": side,
+            "decode": decode,
             "pipeline": {"achieved_GBs": round(pipeline_gbs, 2), "frac_of_hbm_peak": round(pipeline_gbs / HBM_PEAK_GBS, 5),
                          "stage_ms_sum_of_launches": {k: round(v, 4) for k, v in stage_ms.items()},
                          "per_stage": per_stage,

@@ -85,7 +85,7 @@ EXPORTS = [
     "felics_read_header", "felics_write_header",
     "felics_decompress", "felics_strerror", "felics_last_error", "felics_set_profiling",
     "felics_stage_count", "felics_stage_name", "felics_get_stage_ms", "felics_get_stage_launches",
-    "felics_lane_count", "felics_decompress_with_header", "felics_get_stats",
+    "felics_lane_count", "felics_decompress_with_header", "felics_get_stats", "felics_decompress_batch_device",
 ]
 
 _lib = None
@@ -138,6 +138,8 @@ def lib():
     L.felics_decompress.argtypes = [vp, sz, vp, sz, C.POINTER(_CHeader)]
     L.felics_decompress_with_header.argtypes = [vp, sz, C.POINTER(_CHeader), vp, sz]
     L.felics_get_stats.argtypes = [vp, C.POINTER(_CStats)]
+    L.felics_decompress_batch_device.argtypes = [vp, sz, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp, sz,
+                                                 C.POINTER(_CHeader), C.POINTER(C.c_int)]
     L.felics_strerror.argtypes = [C.c_int]
     L.felics_strerror.restype = C.c_char_p
     L.felics_last_error.argtypes = [vp]
@@ -263,6 +265,25 @@ class Encoder:
         if rc != 0:
             self._raise(rc)
         return offs, lens
+
+    def decompress_batch_device(self, d_streams, offsets, lens, d_pixels, d_pixels_cap):
+        """GPU decoder (felics_decompress_batch_device): streams and pixels in device memory (raw pointers).
+        Returns (Header, status array); raises DecompressionError with the first failing stream's code."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint64)
+        n = len(offsets)
+        status = np.zeros(n, dtype=np.int32)
+        ch = _CHeader()
+        rc = lib().felics_decompress_batch_device(
+            self._h, n, d_streams, offsets.ctypes.data_as(C.POINTER(C.c_uint64)), lens.ctypes.data_as(C.POINTER(C.c_uint64)),
+            d_pixels, d_pixels_cap, C.byref(ch), status.ctypes.data_as(C.POINTER(C.c_int)))
+        if rc in DecompressionError.KINDS:
+            err = DecompressionError(rc)
+            err.status = status
+            raise err
+        if rc != 0:
+            self._raise(rc)
+        return Header(ch.color_type, ch.pixel_depth, ch.width, ch.height), status
 
     def stats(self):
         """felics_get_stats: batches redone (slot overflow, look-back fallback), slow-path / failed flags."""

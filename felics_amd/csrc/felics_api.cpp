@@ -107,6 +107,7 @@ struct felics_ctx {
     float stage_ms[ST_COUNT] = {};
     int stage_launches[ST_COUNT] = {};
     DevBuf in, out;  // staging of the host-pointer entry points
+    DevBuf dec_meta, dec_planes;  // GPU decoder: offsets | lens | status of a batch; Y / Co / Cg planes of RGB streams
 };
 
 namespace {
@@ -972,6 +973,8 @@ void felics_ctx_destroy(felics_ctx *ctx) {
     if (ctx->lanes[0].tail) (void)hipStreamDestroy(ctx->lanes[0].tail);
     release(ctx->in);
     release(ctx->out);
+    release(ctx->dec_meta);
+    release(ctx->dec_planes);
     delete ctx;
 }
 
@@ -1140,6 +1143,75 @@ int felics_compress(felics_ctx *ctx, const void *pixels, uint32_t w, uint32_t h,
     int rc = felics_compress_batch(ctx, 1, px, w, h, color, depth, outs, caps, lens);
     *out_len = lens[0];
     return rc;
+}
+
+int felics_decompress_batch_device(felics_ctx *ctx, size_t n, const void *d_streams, const uint64_t *offsets,
+                                   const uint64_t *lens, void *d_pixels, size_t d_pixels_cap, felics_header *hdr_out,
+                                   int *status) {
+    if (!ctx || (n && (!d_streams || !offsets || !lens || !status))) return FELICS_E_INVALID_ARGUMENT;
+    if (ctx->failed) return FELICS_E_HIP;
+    if (n == 0) return FELICS_OK;
+    if (any_pending(ctx)) return FELICS_E_INVALID_ARGUMENT;  // felics_wait_batch first
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Lane &l = ctx->lanes[0];
+    // the shape every stream must have: header of stream 0
+    uint8_t h0[FELICS_HEADER_BYTES] = {0};
+    const size_t hl = (size_t)std::min<uint64_t>(lens[0], FELICS_HEADER_BYTES);
+    if (hl) HIP_TRY(ctx, hipMemcpy(h0, (const uint8_t *)d_streams + offsets[0], hl, hipMemcpyDeviceToHost));
+    felics_header hdr;
+    int rc = felics_read_header(h0, hl, &hdr);
+    if (rc) {
+        status[0] = rc;
+        return rc;
+    }
+    if (hdr_out) *hdr_out = hdr;
+    const uint32_t planes = hdr.color_type == FELICS_COLOR_RGB ? 3 : 1;
+    const size_t bps = hdr.pixel_depth == FELICS_DEPTH_16 ? 2 : 1;
+    const uint64_t npix = (uint64_t)hdr.width * hdr.height;
+    if (npix > 0xFFFFFFFFull) return FELICS_E_INVALID_DIMENSIONS;
+    const uint64_t frame_bytes = npix * planes * bps;
+    if (frame_bytes * n > d_pixels_cap) return FELICS_E_BUFFER_TOO_SMALL;
+    if (frame_bytes && !d_pixels) return FELICS_E_INVALID_ARGUMENT;
+    if (bps == 2 || decode8_lds_bytes(hdr.width) > STRIPE_LDS_LIMIT) {
+        // host decoder, stream by stream
+        std::vector<uint8_t> sbuf, pbuf((size_t)frame_bytes);
+        int first_rc = FELICS_OK;
+        for (size_t i = 0; i < n; i++) {
+            sbuf.resize((size_t)lens[i]);
+            if (lens[i]) HIP_TRY(ctx, hipMemcpy(sbuf.data(), (const uint8_t *)d_streams + offsets[i], (size_t)lens[i], hipMemcpyDeviceToHost));
+            felics_header hi;
+            int r = felics_read_header(sbuf.data(), sbuf.size(), &hi);
+            if (!r && (hi.width != hdr.width || hi.height != hdr.height || hi.color_type != hdr.color_type || hi.pixel_depth != hdr.pixel_depth))
+                r = FELICS_E_INVALID_DIMENSIONS;
+            if (!r) r = felics_decompress(sbuf.data(), sbuf.size(), pbuf.data(), pbuf.size(), nullptr);
+            if (!r && frame_bytes)
+                HIP_TRY(ctx, hipMemcpy((uint8_t *)d_pixels + i * frame_bytes, pbuf.data(), (size_t)frame_bytes, hipMemcpyHostToDevice));
+            status[i] = r;
+            if (r && !first_rc) first_rc = r;
+        }
+        return first_rc;
+    }
+    // offsets | lens | status on the device
+    const size_t meta = n * 8 * 2 + n * 4;
+    if ((rc = reserve(ctx, ctx->dec_meta, meta)) != 0) return rc;
+    uint64_t *d_off = (uint64_t *)ctx->dec_meta.p, *d_len = d_off + n;
+    int *d_status = (int *)(d_len + n);
+    int16_t *d_planes = nullptr;
+    if (planes == 3) {
+        if ((rc = reserve(ctx, ctx->dec_planes, (size_t)(npix * 3 * 2 * n) + 64)) != 0) return rc;
+        d_planes = (int16_t *)ctx->dec_planes.p;
+    }
+    hipStream_t s = l.stream;
+    HIP_TRY(ctx, hipMemcpyAsync(d_off, offsets, n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_len, lens, n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemsetAsync(d_status, 0xFF, n * 4, s));
+    HIP_TRY(ctx, launch_decode8(s, (const uint8_t *)d_streams, d_off, d_len, (uint32_t)n, hdr.width, hdr.height, hdr.color_type,
+                                (uint8_t *)d_pixels, d_planes, d_status));
+    HIP_TRY(ctx, hipMemcpyAsync(status, d_status, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    for (size_t i = 0; i < n; i++)
+        if (status[i]) return status[i];
+    return FELICS_OK;
 }
 
 int felics_write_header(const felics_header *hdr, uint8_t *out, size_t cap) {

@@ -1,0 +1,326 @@
+// felics_gpudecode.hip -- GPU decoder for 8-bit streams (gfx950): decompress_channel of the reference
+// (src/compression.rs:151-248, decode_intensity :48-61) for a whole batch of streams at once.
+//
+// Decoding is bit-serial per stream: the context of a pixel (its two neighbours, misc.rs:6-24) and the
+// Rice parameter (the estimator's state, parameter_selection.rs:49-85) depend on everything decoded
+// before it, and the planes of an RGB image share one bit stream (compression.rs:385-400: plane c + 1
+// starts at the bit plane c ended on).  The only parallelism the format offers is ACROSS streams, so:
+// one wave per stream, the estimator table (512 rows of six counters, 12 KiB) and the two image rows the
+// neighbour rule looks at in LDS, the stream pulled through LDS 256 bytes at a time with coalesced
+// loads, finished rows stored coalesced.  A batch fills the chip from about a thousand streams up; a
+// single stream runs at the speed of one lane.
+//
+// Valid streams decode to exactly the pixels the host decoder (felics_decode.cpp) produces.  Corrupt
+// streams end with an error status (the code can differ from the host decoder's where both a range and a
+// length check would fire), never with an out-of-bounds access: every read of the stream is bounded by its
+// length and every pixel by the image size.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/felics.h"
+#include "felics_device.h"
+#include "felics_kernels.h"
+
+namespace felics {
+
+namespace {
+
+constexpr uint32_t CHUNK_DW = 64;  // dwords of the stream staged in LDS at a time
+
+// MSB-first bit reader over [base, base + len) in global memory (bitstream-io BitReader<_, BigEndian>).
+// Wave-uniform: every lane holds the same state; the 64 lanes only differ when they fetch a chunk.
+struct WaveBits {
+    const uint8_t *base;   // first byte of the bit stream
+    uint64_t len;          // bytes
+    uint64_t next_byte;    // offset of the next byte to stage (multiple of 4 relative to the aligned base)
+    const uint32_t *al;    // aligned-down dword pointer of `base`
+    uint32_t skew;         // base - al, bytes (0..3)
+    uint32_t *chunk;       // LDS, CHUNK_DW dwords
+    uint32_t pos;          // next dword of the chunk to consume
+    uint32_t have;         // dwords in the chunk
+    uint64_t acc;          // unread bits, left-aligned
+    uint32_t navail;       // valid bits in acc
+    uint64_t consumed;     // bits handed out so far
+    bool failed;           // read past the end (DecompressionError::IoError)
+
+    __device__ __forceinline__ void init(const uint8_t *p, uint64_t n, uint32_t *lds) {
+        base = p;
+        len = n;
+        skew = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u);
+        al = reinterpret_cast<const uint32_t *>(p - skew);
+        next_byte = 0;
+        chunk = lds;
+        pos = have = 0;
+        acc = 0;
+        navail = 0;
+        consumed = 0;
+        failed = false;
+        // the first dword may start before the stream: drop the skew bytes
+        refill();
+        if (skew) {
+            acc <<= 8u * skew;
+            navail -= 8u * skew;
+        }
+    }
+    __device__ __forceinline__ void stage() {  // next CHUNK_DW aligned dwords -> LDS (zero past the end)
+        const uint32_t lane = lane_id();
+        const uint64_t total_dw = (skew + len + 3u) >> 2;
+        const uint64_t first = next_byte >> 2;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t v = 0;
+        if (first + lane < total_dw) v = al[first + lane];
+        chunk[lane] = __builtin_bswap32(v);  // big-endian bit order: first byte on top
+        __builtin_amdgcn_wave_barrier();
+        have = (uint32_t)(total_dw - first < CHUNK_DW ? total_dw - first : CHUNK_DW);
+        pos = 0;
+        next_byte += (uint64_t)CHUNK_DW * 4u;
+    }
+    __device__ __forceinline__ void refill() {  // keep at least 32 bits in acc (zeros past the end)
+        while (navail <= 32) {
+            if (pos == have) {
+                if (have != 0 && have < CHUNK_DW) {  // the stream is exhausted: feed zeros
+                    navail += 32;
+                    continue;
+                }
+                stage();
+                if (have == 0) {
+                    have = 1;  // nothing left at all: one dword of zeros per call from here on
+                    chunk[0] = 0;
+                }
+            }
+            acc |= (uint64_t)chunk[pos++] << (32u - navail);
+            navail += 32;
+        }
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t n) {  // n <= 32
+        if (n == 0) return 0;
+        refill();
+        const uint32_t v = (uint32_t)(acc >> (64u - n));
+        acc <<= n;
+        navail -= n;
+        consumed += n;
+        if (consumed > len * 8u) failed = true;
+        return v;
+    }
+    __device__ __forceinline__ uint64_t unary0() {  // ones before the first zero (read_unary0)
+        uint64_t q = 0;
+        while (true) {
+            refill();
+            const uint32_t top = (uint32_t)(acc >> 32);
+            const uint32_t ones = top == 0xFFFFFFFFu ? 32u : (uint32_t)__clz((int)~top);
+            if (ones == 32) {
+                q += 32;
+                acc <<= 32;
+                navail -= 32;
+                consumed += 32;
+                if (consumed > len * 8u) {
+                    failed = true;
+                    return q;
+                }
+                continue;
+            }
+            q += ones;
+            acc <<= ones + 1;
+            navail -= ones + 1;
+            consumed += ones + 1;
+            if (consumed > len * 8u) failed = true;
+            return q;
+        }
+    }
+};
+
+}  // namespace
+
+// One wave per stream.  status[i] = FELICS_OK or an error code.  Gray: u8 pixels straight to `pixels`;
+// RGB: the three planes as int16 to `planes` (image i at i * 3 * npix), converted by k_ycocg8_to_rgb.
+// LDS (dynamic): table 512 x 6 u32 | rows 2 x (W + 2) i16 | chunk.
+__global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ streams, const uint64_t *__restrict__ offsets,
+                                                const uint64_t *__restrict__ lens, uint32_t W, uint32_t H, uint32_t color,
+                                                uint8_t *__restrict__ pixels, int16_t *__restrict__ planes,
+                                                int *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *table = reinterpret_cast<uint32_t *>(smem);
+    int16_t *rows = reinterpret_cast<int16_t *>(smem + NCTX * 6 * 4);
+    const uint32_t rstride = (W + 2u + 1u) & ~1u;
+    uint32_t *chunk = reinterpret_cast<uint32_t *>(smem + NCTX * 6 * 4 + 2u * rstride * 2u);
+    const uint32_t img = blockIdx.x, lane = lane_id();
+    const uint8_t *s = streams + offsets[img];
+    const uint64_t slen = lens[img];
+    const uint64_t npix = (uint64_t)W * H;
+    const uint32_t nplanes = color ? 3u : 1u;
+    // header (format.rs:63-84) must be the one the caller announced
+    int rc = FELICS_OK;
+    if (slen < FELICS_HEADER_BYTES) {
+        rc = FELICS_E_IO;
+    } else {
+        const uint32_t w = ((uint32_t)s[6] << 24) | ((uint32_t)s[7] << 16) | ((uint32_t)s[8] << 8) | s[9];
+        const uint32_t h = ((uint32_t)s[10] << 24) | ((uint32_t)s[11] << 16) | ((uint32_t)s[12] << 8) | s[13];
+        if (s[0] != 'F' || s[1] != 'L' || s[2] != 'C' || s[3] != 'S') rc = FELICS_E_INVALID_SIGNATURE;
+        else if (s[4] > 1) rc = FELICS_E_INVALID_COLOR_TYPE;
+        else if (s[5] > 1) rc = FELICS_E_INVALID_PIXEL_DEPTH;
+        else if (s[4] != color || s[5] != 0 || w != W || h != H) rc = FELICS_E_INVALID_DIMENSIONS;
+    }
+    if (rc != FELICS_OK) {
+        if (lane == 0) status[img] = rc;
+        return;
+    }
+    WaveBits br;
+    br.init(s + FELICS_HEADER_BYTES, slen - FELICS_HEADER_BYTES, chunk);
+    for (uint32_t c = 0; c < nplanes && rc == FELICS_OK; c++) {
+        const int32_t p0 = (int32_t)br.get(32), p1 = (int32_t)br.get(32);  // compression.rs:166-167
+        if (br.failed) {
+            rc = FELICS_E_IO;
+            break;
+        }
+        if (npix == 0) continue;
+        for (uint32_t i = lane; i < NCTX * 6; i += 64) table[i] = 0;  // KEstimator::new
+        __builtin_amdgcn_wave_barrier();
+        int16_t *outp = planes ? planes + ((uint64_t)img * nplanes + c) * npix : nullptr;
+        uint8_t *outg = planes ? nullptr : pixels + (uint64_t)img * npix;
+        const int lo_ok = color ? -255 : 0, hi_ok = 255;  // what a sample of this plane can be (Y 0..255, Co / Cg -255..255)
+        // rows: cur = rows + (y & 1) * rstride, prev the other; row y is stored when it is complete
+        uint32_t x = 0, y = 0;
+        int16_t *cur = rows, *prev = rows + rstride;
+        auto flush_row = [&](uint32_t yy, const int16_t *r) {
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t xx = lane; xx < W; xx += 64) {
+                if (outg)
+                    outg[(uint64_t)yy * W + xx] = (uint8_t)r[xx];
+                else
+                    outp[(uint64_t)yy * W + xx] = r[xx];
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        for (uint64_t i = 0; i < npix; i++) {
+            int pv;
+            if (i < 2) {
+                pv = i == 0 ? p0 : p1;
+                if (npix == 1 && i == 0) pv = p0;
+            } else {
+                int v1, v2;  // misc.rs:6-24
+                if (x > 0 && y > 0) {
+                    v1 = cur[x - 1];
+                    v2 = prev[x];
+                } else if (y == 0) {
+                    v1 = cur[x - 1];
+                    v2 = cur[x - 2];
+                } else if (y >= 2) {  // first column: above and two rows up (the row `cur` still holds: it was row y - 2)
+                    v1 = prev[0];
+                    v2 = cur[0];
+                } else {  // pixel (0,1): above and above-right
+                    v1 = prev[0];
+                    v2 = prev[1];
+                }
+                const int hi = max(v1, v2), lo = min(v1, v2);
+                const uint32_t ctx = (uint32_t)(hi - lo);  // <= 510 because every stored sample is in range
+                if (br.get(1)) {  // in range: phased-in code of p - L (phase_in_coding.rs:86-112)
+                    const uint32_t n = ctx + 1;
+                    const uint32_t m = 31u - (uint32_t)__clz((int)n);
+                    const uint32_t right_p = (2u << m) - n, left_p = n - (1u << m);
+                    uint32_t r = br.get(m);
+                    if (r >= right_p) r = (r - right_p) * 2u + right_p + br.get(1);
+                    uint32_t rot = r + left_p;  // rotate_left: (r + left_p) mod n, r < n
+                    if (rot >= n) rot -= n;
+                    pv = lo + (int)rot;
+                } else {
+                    const bool above = br.get(1) != 0;
+                    uint32_t *row = table + ctx * 6;
+                    uint32_t S[6];
+#pragma unroll
+                    for (uint32_t k = 0; k < 6; k++) S[k] = row[k];
+                    // get_k: smallest counter, ties to the largest k (parameter_selection.rs:71-85)
+                    const uint32_t key = min(min(min((S[0] << 3) | 7u, (S[1] << 3) | 6u), min((S[2] << 3) | 5u, (S[3] << 3) | 4u)),
+                                             min((S[4] << 3) | 3u, (S[5] << 3) | 2u));
+                    const uint32_t k = 7u - (key & 7u);
+                    const uint64_t q = br.unary0();
+                    const uint64_t e64 = (q << k) + br.get(k);
+                    if (br.failed) {
+                        rc = FELICS_E_IO;
+                        break;
+                    }
+                    if (e64 > 1024u) {  // no sample of an 8-bit plane is that far from its neighbours
+                        rc = e64 > 0xFFFFFFFFull ? FELICS_E_VALUE_OVERFLOW : FELICS_E_INVALID_VALUE;
+                        break;
+                    }
+                    const uint32_t e = (uint32_t)e64;
+                    uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+                    for (uint32_t kk = 0; kk < 6; kk++) {
+                        S[kk] += (e >> kk) + 1u + kk;
+                        mn = min(mn, S[kk]);
+                    }
+                    const uint32_t hsh = mn > 1024u ? 1u : 0u;
+                    if (lane == 0) {
+#pragma unroll
+                        for (uint32_t kk = 0; kk < 6; kk++) row[kk] = S[kk] >> hsh;
+                    }
+                    pv = above ? hi + (int)e + 1 : lo - (int)e - 1;
+                }
+                if (br.failed) {
+                    rc = FELICS_E_IO;
+                    break;
+                }
+            }
+            if (pv < lo_ok || pv > hi_ok) {  // try_into::<u8>() / the estimator's context bound would fail
+                rc = FELICS_E_INVALID_VALUE;
+                break;
+            }
+            if (lane == 0) cur[x] = (int16_t)pv;
+            __builtin_amdgcn_wave_barrier();
+            if (++x == W) {
+                flush_row(y, cur);
+                x = 0;
+                y++;
+                int16_t *t = cur;
+                cur = prev;
+                prev = t;
+            }
+        }
+    }
+    if (lane == 0) status[img] = rc;
+}
+
+// ycocg_to_rgb (color_transform.rs:20-26) on the decoded planes, range-checked like try_into::<u8>()
+__global__ __launch_bounds__(256) void k_ycocg8_to_rgb(const int16_t *__restrict__ planes, uint8_t *__restrict__ pixels,
+                                                       uint32_t npix, int *__restrict__ status) {
+    const uint32_t img = blockIdx.y;
+    if (status[img] != FELICS_OK) return;
+    const int16_t *pl = planes + (uint64_t)img * 3 * npix;
+    uint8_t *dst = pixels + (uint64_t)img * 3 * npix;
+    bool bad = false;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        const int yv = pl[i], co = pl[(uint64_t)npix + i], cg = pl[2ull * npix + i];
+        const int t = yv - cg / 2;  // `/` truncates toward zero like Rust's
+        const int g = cg + t, b = t - co / 2, r = b + co;
+        if ((r | g | b) < 0 || r > 255 || g > 255 || b > 255) bad = true;
+        dst[(uint64_t)i * 3] = (uint8_t)r;
+        dst[(uint64_t)i * 3 + 1] = (uint8_t)g;
+        dst[(uint64_t)i * 3 + 2] = (uint8_t)b;
+    }
+    if (bad) atomicCAS(&status[img], FELICS_OK, FELICS_E_INVALID_VALUE);
+}
+
+uint32_t decode8_lds_bytes(uint32_t W) {
+    const uint32_t rstride = (W + 2u + 1u) & ~1u;
+    return NCTX * 6 * 4 + 2u * rstride * 2u + CHUNK_DW * 4u;
+}
+
+hipError_t launch_decode8(hipStream_t s, const uint8_t *streams, const uint64_t *offsets, const uint64_t *lens, uint32_t n,
+                          uint32_t W, uint32_t H, uint32_t color, uint8_t *pixels, int16_t *planes, int *status) {
+    if (n == 0) return hipSuccess;
+    const uint32_t lds = decode8_lds_bytes(W);
+    if (lds > 64u * 1024u) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode8),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)STRIPE_LDS_LIMIT);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_decode8, dim3(n), dim3(64), lds, s, streams, offsets, lens, W, H, color, pixels, planes, status);
+    if (color) {
+        const uint64_t npix = (uint64_t)W * H;
+        const uint32_t bx = (uint32_t)std::min<uint64_t>((npix + 255) / 256, 1024u);
+        if (bx) hipLaunchKernelGGL(k_ycocg8_to_rgb, dim3(bx, n), dim3(256), 0, s, planes, pixels, (uint32_t)npix, status);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace felics

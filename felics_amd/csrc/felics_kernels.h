@@ -210,6 +210,12 @@ template <typename T> hipError_t launch_stripe(hipStream_t s, const StripeArgs &
 void launch_join_edges_tiles(hipStream_t s, const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint32_t *edge_first,
                              const uint32_t *edge_last, const PackTarget &to, const Geometry &g, uint32_t ntiles);
 
+// ---- GPU decoder for 8-bit streams (felics_gpudecode.hip): one wave per stream.  status[i] = FELICS_OK or an error
+// code; gray pixels go straight to `pixels`, RGB through int16 planes (image i at i * 3 * npix) + a conversion kernel.
+uint32_t decode8_lds_bytes(uint32_t W);
+hipError_t launch_decode8(hipStream_t s, const uint8_t *streams, const uint64_t *offsets, const uint64_t *lens, uint32_t n,
+                          uint32_t W, uint32_t H, uint32_t color, uint8_t *pixels, int16_t *planes, int *status);
+
 // ---- 16-bit samples (felics_wide.hip): contexts 0..131070 and 15 Rice parameters (traits.rs:35-43).
 // The events of a batch are ordered by (plane, context) with a stable radix sort and every context's
 // chain is replayed by one wave; lengths / pack are the kernels above on u16 / i32 planes.

@@ -131,6 +131,18 @@ int felics_decompress(const uint8_t *in, size_t len, void *pixels, size_t pixels
 int felics_decompress_with_header(const uint8_t *in, size_t len, const felics_header *hdr, void *pixels,
                                   size_t pixels_cap);
 
+/* GPU decoder: n streams of ONE shape resident in device memory (stream i at d_streams + offsets[i], lens[i] bytes:
+ * exactly what felics_compress_batch_device leaves behind) decoded into d_pixels (n frames back to back, the layout
+ * the encoder takes).  offsets / lens / status are HOST arrays of n entries; status[i] is FELICS_OK or the
+ * DecompressionError code of stream i; the function returns the first non-zero status (or a HIP / argument
+ * error).  *hdr (optional) receives the header all streams must share; it is read from stream 0.
+ * Replaces n calls of `decompress_image` (compression.rs:420-441).  The format is bit-serial per stream (and the
+ * planes of an RGB image share one bit stream), so the only parallelism is across streams: one wave per stream
+ * for 8-bit data.  16-bit streams (a 7.9 MB estimator table per plane) are decoded by the host decoder and copied. */
+int felics_decompress_batch_device(felics_ctx *ctx, size_t n, const void *d_streams, const uint64_t *offsets,
+                                   const uint64_t *lens, void *d_pixels, size_t d_pixels_cap, felics_header *hdr,
+                                   int *status);
+
 /* Text for a code above; for FELICS_E_HIP felics_last_error(ctx) has the HIP message. */
 const char *felics_strerror(int code);
 const char *felics_last_error(const felics_ctx *ctx);

@@ -1,0 +1,180 @@
+"""GPU decoder (felics_decompress_batch_device, src/compression.rs:151-248 of the reference): its pixels against the
+oracle's decoder and the original images -- the reference's own round-trip strategy (compression.rs:456-558,
+tests/compress.rs) with the streams produced by the GPU encoder and by the oracle, plus the committed golden
+streams, truncated / corrupted streams (error.rs:4-19) and a full-size batch."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def enc():
+    import felics_amd
+
+    e = felics_amd.Encoder(0)
+    yield e
+    e.close()
+
+
+def _decode_batch(enc, streams, shape, dtype):
+    """streams: list of bytes of one shape -> list of arrays decoded by the GPU decoder."""
+    import torch
+
+    n = len(streams)
+    offs, blob, at = [], bytearray(), 0
+    for s in streams:
+        offs.append(at)
+        blob += s
+        pad = (-len(blob)) % 16
+        blob += bytes(pad)
+        at = len(blob)
+    lens = [len(s) for s in streams]
+    d_in = torch.from_numpy(np.frombuffer(bytes(blob) + bytes(16), dtype=np.uint8).copy()).cuda()
+    per = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    d_px = torch.zeros(max(per * n, 16), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    hdr, status = enc.decompress_batch_device(d_in.data_ptr(), offs, lens, d_px.data_ptr(), per * n)
+    assert (status == 0).all()
+    host = d_px.cpu().numpy()
+    return hdr, [host[i * per:(i + 1) * per].view(dtype).reshape(shape) for i in range(n)]
+
+
+DIMS = [(2, 1), (1, 2), (1, 1), (4, 7), (100, 40), (124, 274), (1447, 8), (44, 1), (1, 100), (680, 480), (3, 3), (0, 5), (5, 0)]
+
+
+def test_roundtrip_reference_shapes(enc, oracle):
+    """compression.rs:500-558: random u8 gray and rgb (and u16 through the host fallback) at the reference's shapes."""
+    rng = np.random.default_rng(5)
+    for w, h in DIMS:
+        for shape, dt, mx in (((h, w), np.uint8, 256), ((h, w, 3), np.uint8, 256), ((h, w), np.uint16, 65536)):
+            imgs = [rng.integers(0, mx, size=shape).astype(dt) for _ in range(3)]
+            smooth = (np.add.outer(np.arange(h), np.arange(w)) // 2 % mx).astype(dt)
+            imgs.append(smooth if len(shape) == 2 else np.stack([smooth, smooth[::-1], (mx - 1) - smooth], -1).copy())
+            streams = [oracle.compress(im) for im in imgs]
+            hdr, back = _decode_batch(enc, streams, shape, dt)
+            assert (hdr.width, hdr.height) == (w, h)
+            for im, b, s in zip(imgs, back, streams):
+                assert (b == im).all(), (w, h, shape, dt)
+                assert (b == oracle.decompress(s)).all()
+
+
+def test_every_small_shape(enc, oracle):
+    """compression.rs:544-558: every w, h below 12, gray and rgb, one batch per shape."""
+    rng = np.random.default_rng(6)
+    for w in range(1, 12):
+        for h in range(1, 12):
+            for shape in ((h, w), (h, w, 3)):
+                imgs = [rng.integers(0, 256, size=shape, dtype=np.uint8) for _ in range(2)]
+                _, back = _decode_batch(enc, [oracle.compress(im) for im in imgs], shape, np.uint8)
+                assert all((b == im).all() for b, im in zip(back, imgs)), (w, h, shape)
+
+
+def test_extreme_content_and_golden(enc, oracle):
+    from PIL import Image
+
+    rng = np.random.default_rng(7)
+    h, w = 96, 257
+    flat = np.full((h, w), 7, np.uint8)
+    spikes = flat.copy()
+    spikes[rng.integers(0, h, 200), rng.integers(0, w, 200)] = 255  # long unary runs at k = 0
+    checker = ((np.indices((h, w)).sum(0) & 1) * 255).astype(np.uint8)
+    ramp = (np.arange(w)[None, :] + np.arange(h)[:, None]).astype(np.uint8)
+    imgs = [flat, spikes, checker, ramp]
+    _, back = _decode_batch(enc, [oracle.compress(im) for im in imgs], (h, w), np.uint8)
+    assert all((b == im).all() for b, im in zip(back, imgs))
+    rgb = [np.stack([im, im[::-1], 255 - im], -1).copy() for im in imgs]
+    _, back = _decode_batch(enc, [oracle.compress(im) for im in rgb], (h, w, 3), np.uint8)
+    assert all((b == im).all() for b, im in zip(back, rgb))
+    for p in sorted(glob.glob(os.path.join(GOLDEN, "*.felics"))):
+        img = np.array(Image.open(p[:-len(".felics")]))
+        _, back = _decode_batch(enc, [open(p, "rb").read()], img.shape, img.dtype)
+        assert (back[0] == img).all(), p
+
+
+def test_corrupt_streams_give_error_codes(enc, oracle):
+    """error.rs:4-19: truncated streams, bad signature / colour / depth, streams of another shape, bit flips.
+    Every stream of the batch gets a status; nothing hangs or faults."""
+    import felics_amd
+    import torch
+
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, size=(60, 70), dtype=np.uint8)
+    good = oracle.compress(img)
+    other = oracle.compress(rng.integers(0, 256, size=(61, 70), dtype=np.uint8))
+    bad = [good[: len(good) // 2], good[:20], b"XLCS" + good[4:], good[:4] + b"\x07" + good[5:], good[:5] + b"\x09" + good[6:], other,
+           good[:30] + b"\xff" * (len(good) - 30), good[:30] + bytes(len(good) - 30)]
+    for _ in range(12):
+        b = bytearray(good)
+        b[int(rng.integers(14, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        bad.append(bytes(b))
+    streams = [good] + bad + [good]
+    offs, blob = [], bytearray()
+    for s in streams:
+        offs.append(len(blob))
+        blob += s + bytes((-len(s)) % 16)
+    d_in = torch.from_numpy(np.frombuffer(bytes(blob) + bytes(16), dtype=np.uint8).copy()).cuda()
+    d_px = torch.zeros(img.size * len(streams), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with pytest.raises(felics_amd.DecompressionError) as ei:
+        enc.decompress_batch_device(d_in.data_ptr(), offs, [len(s) for s in streams], d_px.data_ptr(), d_px.numel())
+    status = ei.value.status
+    assert status[0] == 0 and status[-1] == 0
+    host = d_px.cpu().numpy()
+    assert (host[: img.size].reshape(img.shape) == img).all() and (host[-img.size:].reshape(img.shape) == img).all()
+    assert status[1] == -1 and status[2] == -1          # truncated: IoError
+    assert status[3] == -7 and status[4] == -5 and status[5] == -6 and status[6] == -4
+    for i, s in enumerate(streams[1:-1], start=1):
+        # a flipped bit may still decode to some image; if the host decoder rejects the stream the GPU decoder must too
+        try:
+            want = oracle.decompress(s)
+            host_ok = want.shape == img.shape
+        except Exception:
+            host_ok = False
+        if not host_ok:
+            assert status[i] != 0, i
+        elif status[i] == 0:
+            assert (host[i * img.size:(i + 1) * img.size].reshape(img.shape) == want).all(), i
+
+
+def test_batch_from_the_gpu_encoder(enc, oracle):
+    """Encode on the GPU, decode on the GPU, without the streams leaving HBM: 24 1080p gray frames and 12 RGB frames."""
+    import torch
+    from felics_amd import synth_torch
+
+    for rgb in (False, True):
+        n, w, h = (12, 1280, 720) if rgb else (24, 1920, 1080)
+        ch = 3 if rgb else 1
+        frames = torch.stack([synth_torch.rgb8(w, h, f) if rgb else synth_torch.gray8(w, h, f, "S1" if f % 5 else "S2") for f in range(n)])
+        cap = int(n * w * h * ch * 1.3) + (1 << 20)
+        d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        offs, lens = enc.compress_batch_device(frames.data_ptr(), n, w, h, int(rgb), 0, d_out.data_ptr(), cap)
+        d_px = torch.zeros_like(frames)
+        hdr, status = enc.decompress_batch_device(d_out.data_ptr(), offs, lens, d_px.data_ptr(), d_px.numel())
+        assert (status == 0).all() and (hdr.width, hdr.height, int(hdr.color_type)) == (w, h, int(rgb))
+        assert bool((d_px == frames).all())
+        host = d_out[int(offs[3]): int(offs[3] + lens[3])].cpu().numpy().tobytes()
+        assert (oracle.decompress(host) == frames[3].cpu().numpy()).all()
+
+
+def test_baseline_batch_decodes(enc):
+    """BASELINE config 3's streams (64 synthetic 4K gray frames) decoded back on the GPU: the size-independent
+    round-trip property at full size."""
+    import torch
+    from felics_amd import synth_torch
+
+    n, w, h = 64, 3840, 2160
+    frames = torch.stack([synth_torch.gray8(w, h, f, "S1") for f in range(n)])
+    cap = int(n * w * h * 1.25) + (1 << 20)
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    offs, lens = enc.compress_batch_device(frames.data_ptr(), n, w, h, 0, 0, d_out.data_ptr(), cap)
+    d_px = torch.zeros_like(frames)
+    _, status = enc.decompress_batch_device(d_out.data_ptr(), offs, lens, d_px.data_ptr(), d_px.numel())
+    assert (status == 0).all() and bool((d_px == frames).all())

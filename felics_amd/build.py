@@ -39,7 +39,7 @@ def source_hash():
 
 def build(force=False, quiet=True):
     """make -C csrc all; returns the path of libfelics.so."""
-    targets = [LIB, os.path.join(OUT, "cfelics"), os.path.join(OUT, "dfelics")]
+    targets = [LIB, os.path.join(OUT, "cfelics"), os.path.join(OUT, "dfelics"), os.path.join(OUT, "imgconv")]
     if force or any(_stale(t, sources()) for t in targets):
         cmd = ["make", "-C", CSRC, "all"] + (["-B"] if force else [])
         subprocess.check_call(cmd, stdout=subprocess.DEVNULL if quiet else None)

@@ -1,8 +1,9 @@
 // image_io.h -- the small part of the `image` crate the reference's command lines rely on
 // (src/bin/cfelics.rs:36-44, src/bin/dfelics.rs:45-52): read an image file into 8/16-bit gray or
 // RGB samples, write one back in the format the file extension names.
-// Formats: baseline uncompressed TIFF (II/MM, strips, chunky) -- every file of the reference's
-// image-suite and bench corpus -- and binary PNM (P5/P6).
+// Formats: TIFF (II/MM, strips, chunky; uncompressed -- every file of the reference's image-suite and bench
+// corpus -- or LZW / Deflate / PackBits, with or without the horizontal predictor), PNG (all colour types and
+// bit depths, Adam7 included; read and write) and binary PNM (P5/P6).  zlib does the inflating / deflating.
 #pragma once
 #include <cstdint>
 #include <string>

@@ -520,6 +520,42 @@ def test_cfelics_dfelics_cli(tmp_path):
     assert open(str(tmp_path / "a.felics"), "rb").read() == open(os.path.join(GOLDEN, "aerial.tiff.felics"), "rb").read()
 
 
+def test_cfelics_reads_png_and_compressed_tiff(tmp_path, oracle):
+    """cfelics.rs:36-44 takes whatever `image` decodes: PNG and LZW / Deflate / PackBits TIFF inputs give the stream of
+    the same pixels; dfelics writes PNG by extension (dfelics.rs:45-52); the corpus script runs end to end."""
+    import subprocess
+    import sys
+
+    from PIL import Image
+
+    build = os.path.join(os.path.dirname(os.path.dirname(__file__)), "felics_amd", "_build")
+    for name in ("6.3.09.tiff", "house.tiff", "aerial.tiff"):
+        img = np.array(Image.open(os.path.join(GOLDEN, name)))
+        want = open(os.path.join(GOLDEN, name + ".felics"), "rb").read()
+        variants = {"v.png": {}, "lzw.tiff": {"compression": "tiff_lzw"}, "zip.tiff": {"compression": "tiff_adobe_deflate"},
+                    "pb.tiff": {"compression": "packbits"}}
+        for fn, kw in variants.items():
+            src = str(tmp_path / fn)
+            Image.fromarray(img).save(src, **kw)
+            out = str(tmp_path / (fn + ".fel"))
+            r = subprocess.run([os.path.join(build, "cfelics"), "-i", src, "-o", out], capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout + r.stderr
+            assert open(out, "rb").read() == want, (name, fn)
+        back = str(tmp_path / "back.png")
+        r = subprocess.run([os.path.join(build, "dfelics"), "-i", out, "-o", back], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert (np.array(Image.open(back)) == img).all()
+    rgba = str(tmp_path / "rgba.png")
+    Image.fromarray(np.zeros((4, 4, 4), np.uint8)).save(rgba)
+    r = subprocess.run([os.path.join(build, "cfelics"), "-i", rgba, "-o", str(tmp_path / "x.fel")], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stdout.strip() == "Unsupported image format: Rgba8"  # cfelics.rs:70
+    root = os.path.dirname(os.path.dirname(__file__))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench", "corpus.py"), "--out", str(tmp_path / "corpus")],
+                       capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Compression times:" in r.stdout and '"round_trip": "ok"' in r.stdout
+
+
 def test_odd_geometry(enc, oracle):
     """Widths that are not multiples of 16 (unaligned rows in the tile staging), tiles that end mid-row,
     very narrow and very wide images."""

@@ -115,6 +115,71 @@ def _corpus(dst):
     put("pnm_huge.ppm", b"P6\n4294967295 4294967295\n65535\n")
     put("pnm_overflow.pgm", b"P5\n99999999999 1\n255\n")
     put("empty", b"")
+    # PNG and compressed TIFF (zlib / LZW / PackBits paths of image_io.cpp): valid files, cuts, flips anywhere
+    import io as _io
+
+    from PIL import Image
+
+    smooth = (np.add.outer(np.arange(40), np.arange(53)) * 5 % 256).astype(np.uint8)
+    rgb = np.stack([smooth, smooth[::-1], 255 - smooth], -1).copy()
+    seeds = []
+    for arr, kw in ((smooth, {}), (rgb, {}), (smooth.astype(np.uint16) * 257, {})):
+        b = _io.BytesIO()
+        Image.fromarray(arr).save(b, format="PNG", **kw)
+        seeds.append(("s.png", b.getvalue()))
+    b = _io.BytesIO()
+    Image.fromarray(rgb).quantize(colors=20).save(b, format="PNG")
+    seeds.append(("pal.png", b.getvalue()))
+    for comp in ("tiff_lzw", "tiff_adobe_deflate", "packbits"):
+        for arr in (smooth, rgb):
+            b = _io.BytesIO()
+            Image.fromarray(arr).save(b, format="TIFF", compression=comp)
+            seeds.append((comp + ".tiff", b.getvalue()))
+    for name, blob in seeds:
+        put(name, blob)
+        for cut in (9, 20, 33, 34, 50, len(blob) // 2, len(blob) - 5, len(blob) - 1):
+            put("cut%d_%s" % (cut, name), blob[:cut])
+        for _ in range(30):
+            bb = bytearray(blob)
+            for _ in range(int(rng.integers(1, 3))):
+                bb[int(rng.integers(0, len(bb)))] ^= 1 << int(rng.integers(0, 8))
+            put("flip_" + name, bytes(bb))
+    # PNGs whose chunks are intact (CRCs right) but whose content is not: bad filter bytes, too little / too much
+    # data, flips inside the deflate stream, palette indices without a palette entry, absurd sizes
+    import zlib as _z
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", _z.crc32(t + b))
+
+    def png(w, h, depth, ctype, raw, interlace=0, plte=None, z=None):
+        body = _z.compress(raw) if z is None else z
+        return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace)) +
+                (chunk(b"PLTE", plte) if plte is not None else b"") + chunk(b"IDAT", body) + chunk(b"IEND", b""))
+
+    rows = b"".join(b"\x00" + bytes(range(16)) for _ in range(8))
+    put("v_ok.png", png(16, 8, 8, 0, rows))
+    put("v_filter9.png", png(16, 8, 8, 0, rows.replace(b"\x00\x00\x01", b"\x09\x00\x01", 1)))
+    put("v_short.png", png(16, 8, 8, 0, rows[:-20]))
+    put("v_long.png", png(16, 8, 8, 0, rows + bytes(500)))
+    put("v_pal_noentry.png", png(16, 8, 8, 3, rows, plte=bytes(9)))
+    put("v_pal_missing.png", png(16, 8, 8, 3, rows))
+    put("v_depth3.png", png(16, 8, 3, 0, rows))
+    put("v_huge.png", png(1 << 30, 1 << 30, 16, 6, rows))
+    put("v_wide.png", png(1 << 31, 1, 8, 0, rows))
+    put("v_zero.png", png(0, 8, 8, 0, rows))
+    put("v_a7.png", png(16, 8, 8, 0, rows, interlace=1))
+    put("v_a7_small.png", png(3, 2, 8, 0, b"\x00\x01" * 20, interlace=1))
+    zgood = _z.compress(rows)
+    for _ in range(40):
+        zb = bytearray(zgood)
+        zb[int(rng.integers(0, len(zb)))] ^= 1 << int(rng.integers(0, 8))
+        put("v_zflip.png", png(16, 8, 8, 0, b"", z=bytes(zb)))
+    for _ in range(20):
+        rb = bytearray(rows)
+        rb[int(rng.integers(0, 8)) * 17] = int(rng.integers(0, 256))  # a filter byte
+        put("v_filt.png", png(16, 8, int(rng.choice([8, 16])), int(rng.choice([0, 2, 4, 6])), bytes(rb)))
+    png = seeds[0][1]
+    put("png_dims.png", png[:16] + struct.pack(">II", 1 << 28, 1 << 28) + png[24:])  # (CRC now wrong: refused there)
     return n
 
 
@@ -129,7 +194,7 @@ def test_mutated_corpus_under_sanitizers(tmp_path, fuzz_binary):
     d = tmp_path / "corpus"
     d.mkdir()
     n = _corpus(str(d))
-    assert n > 300
+    assert n > 700
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1:max_allocation_size_mb=2048",
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     r = subprocess.run([fuzz_binary, str(d)], capture_output=True, text=True, timeout=600, env=env)

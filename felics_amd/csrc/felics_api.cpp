@@ -53,7 +53,7 @@ struct Lane {
     size_t h_sizes_cap = 0;
     DevBuf planes, counts, chain_len, chain_base, chain_prog, scalars, sorted_e, pix_of, k_map, block_state, group_bits,
         tile_bits, tile_bitoff, plane_sums, image_bytes, image_off, partial, block_tag, status, edge_first, edge_last, pscratch;
-    DevBuf wkeys[2], wvals[2], e_of, heads, sort_temp;  // 16-bit samples: sort records, Rice operands, chain heads
+    DevBuf wrecs[2], wtile_cnt, wmeta, whist, wdigtot, heads;  // 16-bit samples: event records (sort double buffer), tile counts, plane ranges, digit histograms, chain heads
     DevBuf s_ctl, s_table, s_status, s_stamps;                     // fused tile kernel: control block, estimator tables, look-back words
     bool ran_stripe = false;                             // the sub-batch in flight went through the fused tile kernel
     uint32_t epoch = 0;               // sub-batches this lane has run: block tags are (epoch, slice)
@@ -537,18 +537,15 @@ template <typename T>
 int run_wide(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     const Geometry &g = l.g;
     const size_t nsamples = (size_t)g.nplanes * g.npix;
-    uint32_t plane_bits = 0;
-    while ((1u << plane_bits) < g.nplanes) plane_bits++;
-    const uint32_t key_bits = WIDE_CTX_BITS + plane_bits;
-    const size_t temp_bytes = wide_sort_temp_bytes(nsamples, key_bits);
+    const WideSizes z = wide_sizes(g);
     int rc;
-    for (int i = 0; i < 2; i++) {
-        if ((rc = reserve(ctx, l.wkeys[i], nsamples * 4)) != 0) return rc;
-        if ((rc = reserve(ctx, l.wvals[i], nsamples * 4)) != 0) return rc;
-    }
-    if ((rc = reserve(ctx, l.e_of, nsamples * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, l.heads, nsamples * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, l.sort_temp, temp_bytes + 256)) != 0) return rc;
+    for (int i = 0; i < 2; i++)
+        if ((rc = reserve(ctx, l.wrecs[i], z.rec_bytes)) != 0) return rc;
+    if ((rc = reserve(ctx, l.wtile_cnt, z.tile_cnt_bytes)) != 0) return rc;
+    if ((rc = reserve(ctx, l.wmeta, z.meta_bytes)) != 0) return rc;
+    if ((rc = reserve(ctx, l.whist, z.hist_bytes)) != 0) return rc;
+    if ((rc = reserve(ctx, l.wdigtot, z.digtot_bytes)) != 0) return rc;
+    if ((rc = reserve(ctx, l.heads, z.heads_bytes)) != 0) return rc;
     if ((rc = reserve(ctx, l.scalars, 64)) != 0) return rc;
     if ((rc = reserve(ctx, l.k_map, nsamples + STAGE_PAD)) != 0) return rc;
     if ((rc = reserve(ctx, l.group_bits, (size_t)g.nplanes * g.pack_tiles * PACK_THREADS * sizeof(group_bits_t<T>))) != 0) return rc;
@@ -570,26 +567,24 @@ int run_wide(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     auto *plane_base = plane_carry + g.nplanes;
     auto *nheads = (uint32_t *)l.scalars.p;
     if (ctx->poison) {
-        DevBuf *bufs[] = {&l.wkeys[0], &l.wkeys[1], &l.wvals[0], &l.wvals[1], &l.e_of, &l.heads, &l.k_map,
+        DevBuf *bufs[] = {&l.wrecs[0], &l.wrecs[1], &l.wtile_cnt, &l.wmeta, &l.whist, &l.heads, &l.k_map,
                           &l.group_bits, &l.tile_bits, &l.tile_bitoff};
         for (DevBuf *b : bufs) HIP_TRY(ctx, hipMemsetAsync(b->p, 0xA5, b->cap, s));
     }
-    uint32_t *skeys = nullptr, *svals = nullptr;
     {
-        StageTimer t(ctx, l, ST_WIDE_KEYS, s, true);
-        launch_wide_keys<T>(s, d_planes, (uint32_t *)l.wkeys[0].p, (uint32_t *)l.wvals[0].p, (uint32_t *)l.e_of.p, g);
+        StageTimer t(ctx, l, ST_WIDE_KEYS, s);
+        launch_wide_events<T>(s, d_planes, (uint32_t *)l.wtile_cnt.p, (uint32_t *)l.wmeta.p, (uint64_t *)l.wrecs[0].p, g);
     }
     {
         StageTimer t(ctx, l, ST_WIDE_SORT, s);
-        HIP_TRY(ctx, wide_sort(s, l.sort_temp.p, temp_bytes, (uint32_t *)l.wkeys[0].p, (uint32_t *)l.wkeys[1].p,
-                               (uint32_t *)l.wvals[0].p, (uint32_t *)l.wvals[1].p, nsamples, key_bits, &skeys, &svals));
+        launch_wide_sort(s, (uint64_t *)l.wrecs[0].p, (uint64_t *)l.wrecs[1].p, (const uint32_t *)l.wmeta.p, (uint32_t *)l.whist.p,
+                         (uint32_t *)l.wdigtot.p, g);
     }
     {
         StageTimer t(ctx, l, ST_WIDE_CHAINS, s);
         HIP_TRY(ctx, hipMemsetAsync(nheads, 0, 4, s));
-        launch_wide_heads(s, skeys, (uint32_t)nsamples, (uint32_t *)l.heads.p, nheads);
-        launch_wide_chains(s, skeys, svals, (const uint32_t *)l.e_of.p, (uint32_t)nsamples, (const uint32_t *)l.heads.p,
-                           nheads, (uint8_t *)l.k_map.p);
+        launch_wide_chains(s, (const uint64_t *)l.wrecs[0].p, (const uint32_t *)l.wmeta.p, (uint64_t *)l.heads.p, nheads,
+                           (uint8_t *)l.k_map.p, g);
     }
     HIP_TRY(ctx, hipMemsetAsync(plane_carry, 0, (size_t)g.nplanes * 16, s));
     {
@@ -665,8 +660,8 @@ size_t max_images_per_pass(uint64_t npix, uint32_t planes, int depth) {
     if (per_image == 0) return SIZE_MAX;
     if (const char *e = getenv("FELICS_TEST_PASS_IMAGES"))  // tests: several passes without a 100 GB batch
         return (size_t)std::max(1, atoi(e));
-    if (depth == FELICS_DEPTH_16)  // ~29 bytes of workspace per sample: keep a pass near 2^30 samples
-        return (size_t)std::max<uint64_t>(1, std::min<uint64_t>(0x40000000ull / per_image, WIDE_MAX_PLANES / planes));
+    if (depth == FELICS_DEPTH_16)  // ~30 bytes of workspace per sample: keep a pass near 2^30 samples
+        return (size_t)std::max<uint64_t>(1, 0x40000000ull / per_image);
     return (size_t)std::max<uint64_t>(1, 0xE0000000ull / (per_image + 64ull * planes * NCTX));
 }
 
@@ -740,6 +735,7 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
     const uint64_t npix = (uint64_t)w * h;
     const bool wide = depth == FELICS_DEPTH_16;
     if (npix * planes >= 0xE0000000ull) return FELICS_E_UNSUPPORTED;
+    if (wide && npix > WIDE_MAX_PLANE_PIXELS) return FELICS_E_UNSUPPORTED;  // an event record keeps the sample index in 29 bits
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int i = 0; i < ST_COUNT; i++) l.ev_used[i] = 0;
     const bool own_out = d_out == nullptr;
@@ -952,8 +948,8 @@ void felics_ctx_destroy(felics_ctx *ctx) {
     for (Lane &l : ctx->lanes) {
         DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map,
                           &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.plane_sums, &l.image_bytes, &l.image_off,
-                          &l.partial, &l.block_tag, &l.status, &l.edge_first, &l.edge_last, &l.pscratch, &l.wkeys[0], &l.wkeys[1], &l.wvals[0], &l.wvals[1], &l.e_of, &l.heads,
-                          &l.sort_temp, &l.s_ctl, &l.s_table, &l.s_status, &l.s_stamps};
+                          &l.partial, &l.block_tag, &l.status, &l.edge_first, &l.edge_last, &l.pscratch, &l.wrecs[0], &l.wrecs[1], &l.wtile_cnt, &l.wmeta, &l.whist, &l.wdigtot, &l.heads,
+                          &l.s_ctl, &l.s_table, &l.s_status, &l.s_stamps};
         for (DevBuf *b : bufs) release(*b);
         if (l.h_sizes) (void)hipHostFree(l.h_sizes);
         for (int i = 0; i < ST_COUNT; i++)

@@ -217,29 +217,27 @@ hipError_t launch_decode8(hipStream_t s, const uint8_t *streams, const uint64_t 
                           uint32_t W, uint32_t H, uint32_t color, uint8_t *pixels, int16_t *planes, int *status);
 
 // ---- 16-bit samples (felics_wide.hip): contexts 0..131070 and 15 Rice parameters (traits.rs:35-43).
-// The events of a batch are ordered by (plane, context) with a stable radix sort and every context's
-// chain is replayed by one wave; lengths / pack are the kernels above on u16 / i32 planes.
-constexpr uint32_t WIDE_CTX_BITS = 18;                          // contexts fit 17 bits; all-ones = "not an event"
-constexpr uint32_t WIDE_NO_EVENT = (1u << WIDE_CTX_BITS) - 1u;
-constexpr uint32_t WIDE_MAX_PLANES = 1u << (32 - WIDE_CTX_BITS);  // plane index above the context in the sort key
+// The events of a batch are compacted into 64-bit records {context, Rice operand, sample index in its plane},
+// ordered by (plane, context) with a stable radix sort (two 9-bit passes per plane; the records are written plane by
+// plane) and every context's chain is replayed by one wave; lengths / pack are the kernels above on u16 / i32 planes.
+constexpr uint32_t WIDE_MAX_PLANE_PIXELS = 1u << 29;  // the sample index in a record has 29 bits
 
 void launch_rgb16_to_planes(hipStream_t s, const uint16_t *rgb, int32_t *planes, uint32_t npix, uint32_t nimg);
 
-// keys[g] = plane << 18 | context (or WIDE_NO_EVENT), vals[g] = g, e_of[g] = the value Rice-coded, for every
-// sample g = plane * npix + i of the batch
+struct WideSizes {
+    uint32_t px_tiles, max_sort_tiles;
+    size_t tile_cnt_bytes, meta_bytes, rec_bytes, hist_bytes, heads_bytes, digtot_bytes;
+};
+WideSizes wide_sizes(const Geometry &g);
+
+// count -> scan -> emit: the records of all events, plane by plane in raster order; meta = totals and per-plane ranges
 template <typename T>
-void launch_wide_keys(hipStream_t s, const T *planes, uint32_t *keys, uint32_t *vals, uint32_t *e_of, const Geometry &g);
-
-// stable sort of (keys, vals) by key; *sorted_keys / *sorted_vals point into the a or b buffers afterwards
-size_t wide_sort_temp_bytes(size_t n, uint32_t key_bits);
-hipError_t wide_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a,
-                     uint32_t *vals_b, size_t n, uint32_t key_bits, uint32_t **sorted_keys, uint32_t **sorted_vals);
-
-// chain heads of the sorted keys -> heads[0 .. *nheads) (unordered); nheads must be zero beforehand
-void launch_wide_heads(hipStream_t s, const uint32_t *keys, uint32_t n, uint32_t *heads, uint32_t *nheads);
-
-// replay of the estimator along every chain: k_map[vals[j]] = k of event j
-void launch_wide_chains(hipStream_t s, const uint32_t *keys, const uint32_t *vals, const uint32_t *e_of, uint32_t n,
-                        const uint32_t *heads, const uint32_t *nheads, uint8_t *k_map);
+void launch_wide_events(hipStream_t s, const T *planes, uint32_t *tile_cnt, uint32_t *meta, uint64_t *recs, const Geometry &g);
+// stable sort by context inside every plane; the result is in recs_a again
+void launch_wide_sort(hipStream_t s, uint64_t *recs_a, uint64_t *recs_b, const uint32_t *meta, uint32_t *hist, uint32_t *dig_tot,
+                      const Geometry &g);
+// chain heads (nheads must be zero beforehand) and the replay of the estimator along every chain: k_map[plane * npix + i] = k
+void launch_wide_chains(hipStream_t s, const uint64_t *recs, const uint32_t *meta, uint64_t *heads, uint32_t *nheads,
+                        uint8_t *k_map, const Geometry &g);
 
 }  // namespace felics

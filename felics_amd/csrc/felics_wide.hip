@@ -2,16 +2,13 @@
 //
 // With u16 samples a context Delta = H - L goes up to 131 070 and the estimator keeps 15 counters
 // per context (traits.rs:35-43), so the per-tile context histograms of the 8-bit pipeline do not
-// apply.  Here the out-of-range EVENTS of the whole batch are ordered by (plane, context) with one
-// stable radix sort (rocPRIM), which turns every context's events into one contiguous CHAIN in
-// raster order; one wave then replays the estimator (parameter_selection.rs:49-85) along each
+// apply.  Here the out-of-range EVENTS of the whole batch are compacted into 64-bit records and ordered by
+// (plane, context) with a stable two-pass radix sort of our own, which turns every context's events into
+// one contiguous CHAIN in raster order; one wave then replays the estimator (parameter_selection.rs:49-85) along each
 // chain, 64 events at a time.  The result is the same k_map (k of every out-of-range pixel, raster
 // order) the 8-bit pipeline produces, and lengths / bitscan / pack of felics_kernels.hip take over.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/types/double_buffer.hpp>
 
 #include "felics_device.h"
 #include "felics_kernels.h"
@@ -40,48 +37,307 @@ __global__ void k_rgb16_to_planes(const uint16_t *__restrict__ rgb, int32_t *__r
     }
 }
 
-// One sort record per sample.  Samples that are not events (in range, or one of the two raw
-// pixels) get the largest context of their plane, so they end up behind the plane's chains.
-template <typename T>
-__global__ __launch_bounds__(256) void k_wide_keys(const T *__restrict__ planes, uint32_t *__restrict__ keys,
-                                                   uint32_t *__restrict__ vals, uint32_t *__restrict__ e_of, uint32_t W,
-                                                   uint32_t npix) {
-    const uint32_t plane = blockIdx.y;
-    const T *pl = planes + (uint64_t)plane * npix;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
-        uint32_t key = (plane << WIDE_CTX_BITS) | WIDE_NO_EVENT, e = 0;
+// ------------------------------------------------------------------------------------------
+// Events, compacted and sorted.  One 64-bit record per out-of-range sample:
+//     bits 0..17   context Delta = H - L            (<= 131 070)
+//     bits 18..34  the value that gets Rice-coded   (<= 131 069)
+//     bits 35..63  the sample's index in its plane  (< 2^29: the host bounds the image size)
+// The records are written plane by plane in raster order (count -> scan -> emit), then sorted by
+// context inside every plane with a stable LSD radix sort of two 9-bit digits (histogram per tile of
+// WT records -> scan per plane -> scatter), so that every (plane, context) chain is contiguous and in
+// raster order.  Written from scratch for this path: no library sort.
+// ------------------------------------------------------------------------------------------
+
+constexpr uint32_t WT = 4096;       // samples per tile (count / emit), records per tile (sort passes)
+constexpr uint32_t WTHREADS = 256;  // threads per tile: 16 samples / records each
+constexpr uint32_t WDIG = 512;      // 9-bit digits
+constexpr uint32_t REC_CTX_BITS = 18, REC_E_BITS = 17;
+
+__device__ __forceinline__ uint64_t make_rec(uint32_t ctx, uint32_t e, uint32_t pix) {
+    return (uint64_t)ctx | ((uint64_t)e << REC_CTX_BITS) | ((uint64_t)pix << (REC_CTX_BITS + REC_E_BITS));
+}
+__device__ __forceinline__ uint32_t rec_ctx(uint64_t r) { return (uint32_t)r & ((1u << REC_CTX_BITS) - 1u); }
+__device__ __forceinline__ uint32_t rec_e(uint64_t r) { return (uint32_t)(r >> REC_CTX_BITS) & ((1u << REC_E_BITS) - 1u); }
+__device__ __forceinline__ uint32_t rec_pix(uint64_t r) { return (uint32_t)(r >> (REC_CTX_BITS + REC_E_BITS)); }
+
+// exclusive prefix of v over the WTHREADS threads of a workgroup (wsum: 4 words of LDS); *total = sum
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, uint32_t *total) {
+    const uint32_t inc = wave_incl_scan(v);
+    const uint32_t wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane_id() == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+    for (uint32_t w = 0; w < WTHREADS / 64; w++) {
+        if (w < wave) off += wsum[w];
+        tot += wsum[w];
+    }
+    *total = tot;
+    return off + inc - v;
+}
+
+// thread t of tile (blockIdx.x, plane blockIdx.y) owns the 16 consecutive samples first .. first + 15
+template <typename T, typename F>
+__device__ __forceinline__ void for_my_events(const T *__restrict__ pl, uint32_t W, uint32_t npix, F &&f) {
+    const uint32_t first = blockIdx.x * WT + threadIdx.x * 16u;
+    if (first >= npix) return;
+    Coord xy;
+    xy.set(first, W);
+    for (uint32_t j = 0; j < 16u && first + j < npix; j++) {
+        const uint32_t i = first + j;
         if (i >= 2) {
-            const uint32_t y = i / W, x = i - y * W;
-            const PixelClass pc = classify(pl, i, x, y, W);
-            if (pc.cls != CLS_IN) {
-                key = (plane << WIDE_CTX_BITS) | pc.ctx;
-                e = pc.val;
-            }
+            const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
+            if (pc.cls != CLS_IN) f(i, pc);
         }
-        const uint32_t g = plane * npix + i;  // < 2^32: the host bounds the batch
-        keys[g] = key;
-        vals[g] = g;
-        e_of[g] = e;
+        xy.advance(1, W);
     }
 }
 
-// Position j starts a chain if it is an event and the key before it differs.
-__global__ __launch_bounds__(256) void k_wide_heads(const uint32_t *__restrict__ keys, uint32_t n,
-                                                    uint32_t *__restrict__ heads, uint32_t *__restrict__ nheads) {
-    const uint32_t nwaves_total = (n + 63u) / 64u;
-    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nwaves_total; w += (gridDim.x * blockDim.x) >> 6) {
-        const uint32_t j = w * 64u + lane_id();
-        bool head = false;
-        if (j < n) {
-            const uint32_t k = keys[j];
-            head = (k & WIDE_NO_EVENT) != WIDE_NO_EVENT && (j == 0 || keys[j - 1] != k);
+template <typename T>
+__global__ __launch_bounds__(WTHREADS) void k_wide_count(const T *__restrict__ planes, uint32_t W, uint32_t npix,
+                                                         uint32_t *__restrict__ tile_cnt) {
+    __shared__ uint32_t wsum[WTHREADS / 64];
+    const T *pl = planes + (uint64_t)blockIdx.y * npix;
+    uint32_t n = 0;
+    for_my_events(pl, W, npix, [&](uint32_t, const PixelClass &) { n++; });
+    uint32_t total;
+    (void)block_excl_scan(n, wsum, &total);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.y * gridDim.x + blockIdx.x] = total;
+}
+
+// One workgroup: exclusive scan of the tile counts (plane-major) in place; per plane its first record, its
+// number of sort tiles and the first of them.  meta (u32): [0] records in all, [1] sort tiles in all, then
+// plane_ev0[P + 1] at WMETA_EV0, stile_first[P + 1] behind it.
+constexpr uint32_t WMETA_EV0 = 4;
+__global__ __launch_bounds__(1024) void k_wide_plan(uint32_t *__restrict__ tile_cnt, uint32_t ntiles, uint32_t nplanes,
+                                                    uint32_t *__restrict__ meta) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    uint32_t *plane_ev0 = meta + WMETA_EV0, *stile_first = plane_ev0 + nplanes + 1;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const uint32_t n = ntiles * nplanes;
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? tile_cnt[i] : 0;
+        const uint32_t inc = wave_incl_scan(v);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
+        const uint32_t c = carry;
+        if (i < n) {
+            tile_cnt[i] = c + woff + inc - v;
+            if (i % ntiles == 0) plane_ev0[i / ntiles] = c + woff + inc - v;
         }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        plane_ev0[nplanes] = carry;
+        meta[0] = carry;
+        uint32_t st = 0;
+        for (uint32_t p = 0; p < nplanes; p++) {  // (a few hundred planes at most)
+            stile_first[p] = st;
+            st += (plane_ev0[p + 1] - plane_ev0[p] + WT - 1) / WT;
+        }
+        stile_first[nplanes] = st;
+        meta[1] = st;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(WTHREADS) void k_wide_emit(const T *__restrict__ planes, uint32_t W, uint32_t npix,
+                                                        const uint32_t *__restrict__ tile_base, uint64_t *__restrict__ recs) {
+    __shared__ uint32_t wsum[WTHREADS / 64];
+    const T *pl = planes + (uint64_t)blockIdx.y * npix;
+    // classify once: the thread's records wait in registers for their place (raster order: thread by thread)
+    uint64_t mine[16];
+    uint32_t n = 0;
+    {
+        const uint32_t first = blockIdx.x * WT + threadIdx.x * 16u;
+        Coord xy;
+        xy.set(first < npix ? first : 0u, W);
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; j++) {
+            const uint32_t i = first + j;
+            mine[j] = ~0ull;
+            if (i < npix && i >= 2) {
+                const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
+                if (pc.cls != CLS_IN) {
+                    mine[j] = make_rec(pc.ctx, pc.val, i);
+                    n++;
+                }
+            }
+            xy.advance(1, W);
+        }
+    }
+    uint32_t total;
+    uint32_t at = tile_base[blockIdx.y * gridDim.x + blockIdx.x] + block_excl_scan(n, wsum, &total);
+#pragma unroll
+    for (uint32_t j = 0; j < 16u; j++)
+        if (mine[j] != ~0ull) recs[at++] = mine[j];
+}
+
+// Which plane a sort tile belongs to, and its record range.
+struct SortTile {
+    uint32_t plane, t, ntile, begin, end;
+};
+__device__ __forceinline__ bool sort_tile(const uint32_t *__restrict__ meta, uint32_t nplanes, uint32_t tile, SortTile &st) {
+    const uint32_t *plane_ev0 = meta + WMETA_EV0, *stile_first = plane_ev0 + nplanes + 1;
+    if (tile >= meta[1]) return false;
+    uint32_t lo = 0, hi = nplanes;  // last plane whose first tile is <= tile (planes without events share their successor's)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (stile_first[mid] <= tile) lo = mid; else hi = mid;
+    }
+    st.plane = lo;
+    st.t = tile - stile_first[lo];
+    st.ntile = stile_first[lo + 1] - stile_first[lo];
+    st.begin = plane_ev0[lo] + st.t * WT;
+    st.end = min(st.begin + WT, plane_ev0[lo + 1]);
+    return true;
+}
+
+// histogram of one digit per sort tile: hist[(WDIG * stile_first[plane]) + digit * ntile + t]
+__global__ __launch_bounds__(WTHREADS) void k_wsort_hist(const uint64_t *__restrict__ recs, const uint32_t *__restrict__ meta,
+                                                         uint32_t nplanes, uint32_t shift, uint32_t *__restrict__ hist,
+                                                         uint32_t *__restrict__ dig_tot) {
+    __shared__ uint32_t h[WDIG];
+    SortTile st;
+    if (!sort_tile(meta, nplanes, blockIdx.x, st)) return;
+    for (uint32_t d = threadIdx.x; d < WDIG; d += WTHREADS) h[d] = 0;
+    __syncthreads();
+    for (uint32_t j = st.begin + threadIdx.x; j < st.end; j += WTHREADS) atomicAdd(&h[(rec_ctx(recs[j]) >> shift) & (WDIG - 1u)], 1u);
+    __syncthreads();
+    const uint32_t *stile_first = meta + WMETA_EV0 + nplanes + 1;
+    uint32_t *dst = hist + (uint64_t)WDIG * stile_first[st.plane];
+    for (uint32_t d = threadIdx.x; d < WDIG; d += WTHREADS) {
+        dst[(uint64_t)d * st.ntile + st.t] = h[d];
+        if (h[d]) atomicAdd(&dig_tot[st.plane * WDIG + d], h[d]);  // per (plane, digit): lets the scan start anywhere
+    }
+}
+
+// per plane: exclusive scan of its histogram matrix in (digit, tile) order, on top of the plane's first record.
+// A workgroup takes WSCAN_DIGITS consecutive digits of one plane; where they start comes from the per-digit totals.
+constexpr uint32_t WSCAN_DIGITS = 16;
+__global__ __launch_bounds__(1024) void k_wsort_scan(uint32_t *__restrict__ hist, const uint32_t *__restrict__ meta, uint32_t nplanes,
+                                                     const uint32_t *__restrict__ dig_tot) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const uint32_t *plane_ev0 = meta + WMETA_EV0, *stile_first = plane_ev0 + nplanes + 1;
+    const uint32_t plane = blockIdx.y, d0 = blockIdx.x * WSCAN_DIGITS;
+    const uint32_t ntile = stile_first[plane + 1] - stile_first[plane];
+    if (ntile == 0) return;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    {  // records of this plane with a smaller digit
+        const uint32_t v = threadIdx.x < d0 ? dig_tot[plane * WDIG + threadIdx.x] : 0u;  // d0 <= 512 < 1024 threads
+        const uint32_t inc = wave_incl_scan(v);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t c = plane_ev0[plane];
+            for (uint32_t w = 0; w < 16; w++) c += wsum[w];
+            carry = c;
+        }
+        __syncthreads();
+    }
+    uint32_t *m = hist + (uint64_t)WDIG * stile_first[plane] + (uint64_t)d0 * ntile;
+    const uint32_t n = WSCAN_DIGITS * ntile;
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? m[i] : 0;
+        const uint32_t inc = wave_incl_scan(v);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
+        const uint32_t c = carry;
+        if (i < n) m[i] = c + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + woff + inc;
+        __syncthreads();
+    }
+}
+
+// Stable scatter of one digit.  Wave w of a tile owns records [w * 1024, (w + 1) * 1024) of it, 64 at a time in
+// order; the lanes that share a digit rank themselves with one ballot per digit bit.
+__global__ __launch_bounds__(WTHREADS) void k_wsort_scatter(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst,
+                                                            const uint32_t *__restrict__ meta, uint32_t nplanes, uint32_t shift,
+                                                            const uint32_t *__restrict__ hist) {
+    __shared__ uint32_t run[WTHREADS / 64][WDIG];
+    SortTile st;
+    if (!sort_tile(meta, nplanes, blockIdx.x, st)) return;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    for (uint32_t d = threadIdx.x; d < WDIG * (WTHREADS / 64); d += WTHREADS) (&run[0][0])[d] = 0;
+    __syncthreads();
+    // this wave's records, batch b = records w * 1024 + b * 64 + lane
+    uint64_t rec[16];
+    const uint32_t wfirst = st.begin + wave * 1024u;
+#pragma unroll
+    for (uint32_t b = 0; b < 16; b++) {
+        const uint32_t j = wfirst + b * 64u + lane;
+        rec[b] = j < st.end ? src[j] : ~0ull;
+        if (j < st.end) atomicAdd(&run[wave][(rec_ctx(rec[b]) >> shift) & (WDIG - 1u)], 1u);
+    }
+    __syncthreads();
+    // counts -> where each wave's records of each digit go
+    const uint32_t *stile_first = meta + WMETA_EV0 + nplanes + 1;
+    const uint32_t *off = hist + (uint64_t)WDIG * stile_first[st.plane];
+    for (uint32_t d = threadIdx.x; d < WDIG; d += WTHREADS) {
+        uint32_t at = off[(uint64_t)d * st.ntile + st.t];
+        for (uint32_t w = 0; w < WTHREADS / 64; w++) {
+            const uint32_t c = run[w][d];
+            run[w][d] = at;
+            at += c;
+        }
+    }
+    __syncthreads();
+    uint32_t *myrun = run[wave];
+#pragma unroll
+    for (uint32_t b = 0; b < 16; b++) {
+        const bool ev = wfirst + b * 64u + lane < st.end;
+        if (__ballot(ev) == 0) break;
+        const uint32_t d = (rec_ctx(rec[b]) >> shift) & (WDIG - 1u);
+        const uint64_t ev_mask = __ballot(ev);
+        uint32_t m_lo = (uint32_t)ev_mask, m_hi = (uint32_t)(ev_mask >> 32);
+#pragma unroll
+        for (uint32_t bit = 0; bit < 9; bit++) {
+            const uint32_t t = (uint32_t)((int32_t)(d << (31 - bit)) >> 31);  // all ones if the bit is set
+            const uint64_t bb = __ballot(ev && t != 0);
+            m_lo &= ~((uint32_t)bb ^ t);
+            m_hi &= ~((uint32_t)(bb >> 32) ^ t);
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+        const uint32_t group = (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);
+        uint32_t dest = 0;
+        if (ev) dest = myrun[d] + rank;
+        __builtin_amdgcn_wave_barrier();
+        if (ev && rank == 0) myrun[d] = dest + group;
+        __builtin_amdgcn_wave_barrier();
+        if (ev) dst[dest] = rec[b];
+    }
+}
+
+// chain heads of the sorted records: first record of a plane, or a context different from the one before.
+// heads[h] = record index | plane << 32 (unordered)
+__global__ __launch_bounds__(WTHREADS) void k_wide_heads(const uint64_t *__restrict__ recs, const uint32_t *__restrict__ meta,
+                                                         uint32_t nplanes, uint64_t *__restrict__ heads, uint32_t *__restrict__ nheads) {
+    SortTile st;
+    if (!sort_tile(meta, nplanes, blockIdx.x, st)) return;
+    const uint32_t plane_first = meta[WMETA_EV0 + st.plane];
+    for (uint32_t j0 = st.begin + (threadIdx.x & ~63u); j0 < st.end; j0 += WTHREADS) {
+        const uint32_t j = j0 + lane_id();
+        bool head = false;
+        if (j < st.end) head = j == plane_first || rec_ctx(recs[j]) != rec_ctx(recs[j - 1]);
         const uint64_t m = __ballot(head);
         if (m == 0) continue;
         uint32_t base = 0;
         if (lane_id() == 0) base = atomicAdd(nheads, (uint32_t)__popcll(m));
         base = readlane(base, 0);
-        if (head) heads[base + mbcnt(m)] = j;
+        if (head) heads[base + mbcnt(m)] = (uint64_t)j | ((uint64_t)st.plane << 32);
     }
 }
 
@@ -94,28 +350,34 @@ constexpr uint32_t WIDE_HALVE = 1024;   // COUNT_SCALING (traits.rs:40)
 // :71-85) and after it.  The counters are halved after the first event that lifts their minimum above
 // 1024 (:58-68); that minimum never decreases along the block, so the event is found with one ballot,
 // the counters are halved there and the rest of the block is scanned again from the halved state.
-__global__ __launch_bounds__(256) void k_wide_chains(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                                     const uint32_t *__restrict__ e_of, uint32_t n,
-                                                     const uint32_t *__restrict__ heads,
+// The next block's records are in flight while this one is resolved.
+__global__ __launch_bounds__(256) void k_wide_chains(const uint64_t *__restrict__ recs, const uint32_t *__restrict__ meta,
+                                                     uint32_t nplanes, uint32_t npix, const uint64_t *__restrict__ heads,
                                                      const uint32_t *__restrict__ nheads, uint8_t *__restrict__ k_map) {
     const uint32_t lane = lane_id();
     const uint32_t nchains = *nheads;
     const uint32_t wave0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t c = wave0; c < nchains; c += nwaves) {
-        uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)heads[c]);  // wave-uniform: chain position and counters stay scalar
-        const uint32_t key = keys[j];
+        const uint64_t hd = heads[c];
+        uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hd);  // wave-uniform: chain position and counters stay scalar
+        const uint32_t plane = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(hd >> 32));
+        const uint32_t plane_end = meta[WMETA_EV0 + plane + 1];
+        uint8_t *kp = k_map + (uint64_t)plane * npix;
+        const uint32_t ctx = rec_ctx(recs[j]);
         uint32_t S[WIDE_NK];
 #pragma unroll
         for (int k = 0; k < WIDE_NK; k++) S[k] = 0;
+        uint64_t cur = j + lane < plane_end ? recs[j + lane] : ~0ull;
         for (;;) {
-            const uint32_t idx = j + lane;
-            const bool valid = idx < n && keys[idx] == key;
+            const bool valid = j + lane < plane_end && rec_ctx(cur) == ctx;
             const uint64_t vm = __ballot(valid);  // a prefix of the lanes
             const uint32_t nvalid = (uint32_t)__popcll(vm);
             if (nvalid == 0) break;
-            const uint32_t pix = valid ? vals[idx] : 0u;
-            const uint32_t e = valid ? e_of[pix] : 0u;
+            const uint64_t mine = cur;
+            if (nvalid == 64u) cur = j + 64u + lane < plane_end ? recs[j + 64u + lane] : ~0ull;  // next block, in flight
+            const uint32_t pix = rec_pix(mine);
+            const uint32_t e = valid ? rec_e(mine) : 0u;
             uint32_t base = 0;  // first event of the block not yet resolved
             while (base < nvalid) {
                 const bool live = valid && lane >= base;
@@ -135,7 +397,7 @@ __global__ __launch_bounds__(256) void k_wide_chains(const uint32_t *__restrict_
                 }
                 const uint64_t hm = __ballot(live && after_min > WIDE_HALVE);
                 const uint32_t f = hm ? (uint32_t)__builtin_ctzll(hm) : nvalid - 1u;  // last event served by this scan
-                if (live && lane <= f) k_map[pix] = (uint8_t)best_k;
+                if (live && lane <= f) kp[pix] = (uint8_t)best_k;
 #pragma unroll
                 for (int k = 0; k < WIDE_NK; k++) {
                     const uint32_t s = S[k] + readlane(P[k], f);
@@ -161,40 +423,50 @@ void launch_rgb16_to_planes(hipStream_t s, const uint16_t *rgb, int32_t *planes,
     FELICS_LAUNCH(k_rgb16_to_planes, dim3(blocks), dim3(256), s, rgb, planes, npix, nimg);
 }
 
+WideSizes wide_sizes(const Geometry &g) {
+    WideSizes z;
+    const uint64_t nsamples = (uint64_t)g.nplanes * g.npix;
+    z.px_tiles = cdiv(g.npix, WT);
+    z.max_sort_tiles = (uint32_t)(nsamples / WT + g.nplanes);
+    z.tile_cnt_bytes = (size_t)z.px_tiles * g.nplanes * 4;
+    z.meta_bytes = (size_t)(WMETA_EV0 + 2 * (g.nplanes + 1)) * 4;
+    z.rec_bytes = (size_t)nsamples * 8 + 64;
+    z.hist_bytes = (size_t)z.max_sort_tiles * WDIG * 4;
+    z.heads_bytes = (size_t)nsamples * 8 + 64;
+    z.digtot_bytes = (size_t)g.nplanes * WDIG * 4;
+    return z;
+}
+
 template <typename T>
-void launch_wide_keys(hipStream_t s, const T *planes, uint32_t *keys, uint32_t *vals, uint32_t *e_of, const Geometry &g) {
-    const uint32_t bx = std::min<uint32_t>(cdiv(g.npix, 256), 4096u);
-    FELICS_LAUNCH((k_wide_keys<T>), dim3(bx, g.nplanes), dim3(256), s, planes, keys, vals, e_of, g.W, g.npix);
+void launch_wide_events(hipStream_t s, const T *planes, uint32_t *tile_cnt, uint32_t *meta, uint64_t *recs, const Geometry &g) {
+    const WideSizes z = wide_sizes(g);
+    FELICS_LAUNCH((k_wide_count<T>), dim3(z.px_tiles, g.nplanes), dim3(WTHREADS), s, planes, g.W, g.npix, tile_cnt);
+    FELICS_LAUNCH(k_wide_plan, dim3(1), dim3(1024), s, tile_cnt, z.px_tiles, g.nplanes, meta);
+    FELICS_LAUNCH((k_wide_emit<T>), dim3(z.px_tiles, g.nplanes), dim3(WTHREADS), s, planes, g.W, g.npix, tile_cnt, recs);
 }
-template void launch_wide_keys<uint16_t>(hipStream_t, const uint16_t *, uint32_t *, uint32_t *, uint32_t *,
-                                         const Geometry &);
-template void launch_wide_keys<int32_t>(hipStream_t, const int32_t *, uint32_t *, uint32_t *, uint32_t *, const Geometry &);
+template void launch_wide_events<uint16_t>(hipStream_t, const uint16_t *, uint32_t *, uint32_t *, uint64_t *, const Geometry &);
+template void launch_wide_events<int32_t>(hipStream_t, const int32_t *, uint32_t *, uint32_t *, uint64_t *, const Geometry &);
 
-size_t wide_sort_temp_bytes(size_t n, uint32_t key_bits) {
-    size_t bytes = 0;
-    rocprim::double_buffer<uint32_t> k(nullptr, nullptr), v(nullptr, nullptr);
-    if (rocprim::radix_sort_pairs(nullptr, bytes, k, v, n, 0u, key_bits) != hipSuccess) return 0;
-    return bytes;
-}
-
-hipError_t wide_sort(hipStream_t s, void *temp, size_t temp_bytes, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a,
-                     uint32_t *vals_b, size_t n, uint32_t key_bits, uint32_t **sorted_keys, uint32_t **sorted_vals) {
-    rocprim::double_buffer<uint32_t> k(keys_a, keys_b), v(vals_a, vals_b);
-    const hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, k, v, n, 0u, key_bits, s);
-    *sorted_keys = k.current();
-    *sorted_vals = v.current();
-    return e;
-}
-
-void launch_wide_heads(hipStream_t s, const uint32_t *keys, uint32_t n, uint32_t *heads, uint32_t *nheads) {
-    const uint32_t blocks = std::min<uint32_t>(cdiv(n, 256), 256u * 16u);
-    FELICS_LAUNCH(k_wide_heads, dim3(blocks), dim3(256), s, keys, n, heads, nheads);
+// two stable passes (low, then high nine context bits): the sorted records end up in recs_a again
+void launch_wide_sort(hipStream_t s, uint64_t *recs_a, uint64_t *recs_b, const uint32_t *meta, uint32_t *hist, uint32_t *dig_tot,
+                      const Geometry &g) {
+    const WideSizes z = wide_sizes(g);
+    uint64_t *src = recs_a, *dst = recs_b;
+    for (uint32_t shift = 0; shift < REC_CTX_BITS; shift += 9) {
+        (void)hipMemsetAsync(dig_tot, 0, z.digtot_bytes, s);
+        FELICS_LAUNCH(k_wsort_hist, dim3(z.max_sort_tiles), dim3(WTHREADS), s, src, meta, g.nplanes, shift, hist, dig_tot);
+        FELICS_LAUNCH(k_wsort_scan, dim3(WDIG / WSCAN_DIGITS, g.nplanes), dim3(1024), s, hist, meta, g.nplanes, dig_tot);
+        FELICS_LAUNCH(k_wsort_scatter, dim3(z.max_sort_tiles), dim3(WTHREADS), s, src, dst, meta, g.nplanes, shift, hist);
+        std::swap(src, dst);
+    }
 }
 
-void launch_wide_chains(hipStream_t s, const uint32_t *keys, const uint32_t *vals, const uint32_t *e_of, uint32_t n,
-                        const uint32_t *heads, const uint32_t *nheads, uint8_t *k_map) {
+void launch_wide_chains(hipStream_t s, const uint64_t *recs, const uint32_t *meta, uint64_t *heads, uint32_t *nheads,
+                        uint8_t *k_map, const Geometry &g) {
+    const WideSizes z = wide_sizes(g);
+    FELICS_LAUNCH(k_wide_heads, dim3(z.max_sort_tiles), dim3(WTHREADS), s, recs, meta, g.nplanes, heads, nheads);
     // persistent: 8 workgroups of 4 waves per CU share the chains
-    FELICS_LAUNCH(k_wide_chains, dim3(256u * 8u), dim3(256), s, keys, vals, e_of, n, heads, nheads, k_map);
+    FELICS_LAUNCH(k_wide_chains, dim3(256u * 8u), dim3(256), s, recs, meta, g.nplanes, g.npix, heads, nheads, k_map);
 }
 
 }  // namespace felics

@@ -42,7 +42,7 @@ extern "C" {
 #define FELICS_E_INVALID_SIGNATURE (-7)   /* ::InvalidSignature  */
 #define FELICS_E_BUFFER_TOO_SMALL (-8)    /* caller's output buffer cannot hold the result */
 #define FELICS_E_HIP (-9)                 /* no device / HIP runtime error (see felics_last_error) */
-#define FELICS_E_UNSUPPORTED (-10)        /* valid request this build cannot run on the GPU (one image of >= 3.7 G samples) */
+#define FELICS_E_UNSUPPORTED (-10)        /* valid request this build cannot run on the GPU (one image of >= 3.7 G samples; a 16-bit image of > 2^29 pixels) */
 #define FELICS_E_INVALID_ARGUMENT (-11)   /* NULL pointer, bad enum value */
 
 /* format.rs:8-12 ColorType, format.rs:27-31 PixelDepth (wire values) */

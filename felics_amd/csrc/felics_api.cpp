@@ -90,6 +90,8 @@ struct felics_ctx {
                                 // (felics_stripe.hip) instead of the multi-kernel pipeline.  Measured slower so far,
                                 // hence opt-in; a hand-off of that kernel that gives up moves the context back for good
     uint32_t stripe_wgs = 256;  // workgroups of the persistent kernel: one per CU (its LDS fills a CU); FELICS_STRIPE_WGS
+    bool pack_k = true;         // the single-pass pack computes k itself, in LDS (k_pack_k): no k_assign launches, no k per pixel in HBM.
+                                // FELICS_ASSIGN=kernel selects the separate k_assign kernel + k_map again
     bool two_pass = false;      // FELICS_TWO_PASS=1, or a look-back of the single-pass pack gave up once: lengths + pack kernels
     bool test_stripe_fail = false; // FELICS_TEST_STRIPE_FAIL=1: pretend the first fused-kernel submission gave up (tests)
     bool test_lookback = false; // FELICS_TEST_LOOKBACK_FAIL=1: pretend the first single-pass submission gave up (tests)
@@ -258,7 +260,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     if ((rc = reserve(ctx, l.chain_len, (size_t)g.nplanes * NCTX * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.chain_base, (size_t)g.nplanes * NCTX * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.chain_prog, (size_t)g.nplanes * NCTX * 32)) != 0) return rc;
-    if ((rc = reserve(ctx, l.scalars, 64)) != 0) return rc;
+    if ((rc = reserve(ctx, l.scalars, 64 + 4 * (SLICES + 2))) != 0) return rc;
     if ((rc = reserve(ctx, l.sorted_e, slots * sizeof(ET) + SORTED_PAD)) != 0) return rc;
     if ((rc = reserve(ctx, l.pix_of, slots * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.k_map, nsamples + STAGE_PAD)) != 0) return rc;
@@ -303,6 +305,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     // slots, so the lanes share the tail stream).  It puts planes 1, 2 of an RGB image into scratch slots of
     // their own and moves them behind plane 0 at the end.
     const bool fused = slot_stride != 0 && !ctx->two_pass;
+    const bool ink = fused && ctx->pack_k;  // k inside the pack kernel: the k stream has nothing to do
     // Two-pass kernels: gray frames pack slice by slice; RGB packs after the last slice (the offset of planes
     // 1 and 2 in their stream needs the size of the planes before them).
     const bool pack_by_slice = slot_stride != 0 && g.planes_per_image == 1;
@@ -313,6 +316,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         target.scratch = (uint8_t *)l.pscratch.p;
     }
     uint32_t *d_error = (uint32_t *)l.scalars.p + 8;  // look-back watchdog of the single-pass pack
+    uint32_t *d_tickets = (uint32_t *)l.scalars.p + 16;  // one per pack launch of this sub-batch: tiles are handed out in order
 
     // ---- front stream
     if (ctx->poison) {  // FELICS_POISON: every intermediate buffer starts as garbage, as on a fresh context
@@ -357,7 +361,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         HIP_TRY(ctx, hipEventRecord(l.spine_done[q], s));
     }
     // ---- k stream: behind every spine launch, k of the events it published
-    for (int q = 0; q < ns; q++) {
+    for (int q = 0; q < ns && !ink; q++) {
         HIP_TRY(ctx, hipStreamWaitEvent(ks, l.spine_done[q], 0));
         if (bounds[q + 1] != bounds[q] || q + 1 == ns) {
             StageTimer t(ctx, l, ST_ASSIGN, ks, true);
@@ -370,18 +374,29 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     // ---- tail stream: code lengths, bit offsets and (with fixed slots) the packed bits of each slice's tiles
     HIP_TRY(ctx, hipMemsetAsync(plane_carry, 0, (size_t)g.nplanes * 16, tl));
     HIP_TRY(ctx, hipMemsetAsync(d_error, 0, 4, tl));
+    HIP_TRY(ctx, hipMemsetAsync(d_tickets, 0, 4 * (SLICES + 2), tl));
     for (int q = 0; q < ns; q++) {
-        HIP_TRY(ctx, hipStreamWaitEvent(tl, l.assign_done[q], 0));
         const bool last = q + 1 == ns;
+        HIP_TRY(ctx, hipStreamWaitEvent(tl, ink ? l.spine_done[q] : l.assign_done[q], 0));
         if (bounds[q + 1] == bounds[q] && !last) continue;
-        if (fused) {
+        if (ink) {
+            {
+                StageTimer t(ctx, l, ST_PACK, tl, true);
+                launch_pack_k<T, ET>(tl, d_planes, (const ET *)l.sorted_e.p, (const uint32_t *)l.pix_of.p, (const uint32_t *)l.block_state.p,
+                                     counts, chain_base, chain_len, (uint64_t *)l.status.p, (uint64_t *)l.tile_bitoff.p,
+                                     (uint32_t *)l.tile_bits.p, plane_carry, (uint32_t *)l.edge_first.p, (uint32_t *)l.edge_last.p, d_error,
+                                     target, g, bounds[q], bounds[q + 1], epoch, d_tickets + q);
+            }
+        } else if (fused) {
             {
                 StageTimer t(ctx, l, ST_PACK, tl, true);
                 launch_pack_fused<T>(tl, d_planes, (const uint8_t *)l.k_map.p, (uint64_t *)l.status.p,
                                      (uint64_t *)l.tile_bitoff.p, (uint32_t *)l.tile_bits.p, plane_carry,
                                      (uint32_t *)l.edge_first.p, (uint32_t *)l.edge_last.p, d_error, target, g, pbounds[q],
-                                     pbounds[q + 1], epoch);
+                                     pbounds[q + 1], epoch, d_tickets + q);
             }
+        }
+        if (fused) {
             if (last) {
                 StageTimer t(ctx, l, ST_ZERO, tl);
                 launch_finish_sizes(tl, plane_carry, plane_base, (uint64_t *)l.image_bytes.p, g);
@@ -888,6 +903,7 @@ int felics_ctx_create(int device, felics_ctx **out) {
     ctx->poison = getenv("FELICS_POISON") != nullptr;
     ctx->two_pass = getenv("FELICS_TWO_PASS") != nullptr;
     ctx->test_lookback = getenv("FELICS_TEST_LOOKBACK_FAIL") != nullptr;
+    if (const char *e = getenv("FELICS_ASSIGN")) ctx->pack_k = strcmp(e, "kernel") != 0;
     ctx->test_stripe_fail = getenv("FELICS_TEST_STRIPE_FAIL") != nullptr;
     if (const char *e = getenv("FELICS_PIPELINE")) ctx->stripe = strcmp(e, "stripe") == 0;
     {
@@ -908,8 +924,10 @@ int felics_ctx_create(int device, felics_ctx **out) {
         ok = ok && hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio_high) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&l.front, hipStreamNonBlocking, prio_high) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&l.kstream, hipStreamNonBlocking, prio_low) == hipSuccess;
-        // one tail stream for all lanes: the single-pass pack kernels of two submissions run one after the other
-        if (&l == &ctx->lanes[0])
+        // One tail stream for all lanes: the pack kernels of two submissions run one after the other (measured faster:
+        // 4.6 vs 4.8 ms per step).  FELICS_OWN_TAILS=1 gives every lane its own; that is safe since the pack kernels hand
+        // out their tiles by ticket (FusedArgs::ticket), it just is not faster.
+        if (&l == &ctx->lanes[0] || getenv("FELICS_OWN_TAILS"))
             ok = ok && hipStreamCreateWithPriority(&l.tail, hipStreamNonBlocking, prio_low) == hipSuccess;
         else
             l.tail = ctx->lanes[0].tail;
@@ -944,7 +962,8 @@ void felics_ctx_destroy(felics_ctx *ctx) {
         if (l.stream) (void)hipStreamSynchronize(l.stream);
         if (l.kstream) (void)hipStreamSynchronize(l.kstream);
     }
-    if (ctx->lanes[0].tail) (void)hipStreamSynchronize(ctx->lanes[0].tail);
+    for (Lane &l : ctx->lanes)
+        if (l.tail) (void)hipStreamSynchronize(l.tail);
     for (Lane &l : ctx->lanes) {
         DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map,
                           &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.plane_sums, &l.image_bytes, &l.image_off,
@@ -965,8 +984,8 @@ void felics_ctx_destroy(felics_ctx *ctx) {
         if (l.front) (void)hipStreamDestroy(l.front);
         if (l.kstream) (void)hipStreamDestroy(l.kstream);
         if (l.stream) (void)hipStreamDestroy(l.stream);
+        if (l.tail && (&l == &ctx->lanes[0] || l.tail != ctx->lanes[0].tail)) (void)hipStreamDestroy(l.tail);
     }
-    if (ctx->lanes[0].tail) (void)hipStreamDestroy(ctx->lanes[0].tail);
     release(ctx->in);
     release(ctx->out);
     release(ctx->dec_meta);

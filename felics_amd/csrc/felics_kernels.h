@@ -12,8 +12,9 @@ namespace felics {
 
 // u8 samples (and Y/Co/Cg of RGB8): contexts 0..510 (traits.rs:28), table padded to 512.
 constexpr uint32_t NCTX = 512;
-// pixels one wave partitions by context in the hist / scatter stages
-constexpr uint32_t SORT_TILE = 8192;
+// pixels one wave partitions by context in the hist / scatter stages.  Equal to the pack tile: the pack stage
+// computes k for exactly its own tile's events (k_pack_k), one look-back per workgroup.
+constexpr uint32_t SORT_TILE = 4096;
 // pack stage: 256 threads x 16 consecutive pixels
 constexpr uint32_t PACK_THREADS = 256;
 constexpr uint32_t PACK_PER_THREAD = 16;
@@ -151,7 +152,17 @@ struct PackTarget {
 template <typename T>
 void launch_pack_fused(hipStream_t s, const T *planes, const uint8_t *k_map, uint64_t *status, uint64_t *tile_bitoff,
                        uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last,
-                       uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t t0, uint32_t t1, uint32_t epoch);
+                       uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t t0, uint32_t t1, uint32_t epoch,
+                       uint32_t *ticket /* one zeroed word per launch: tiles are handed out in order */);
+// The same pack with k computed inside it (k_pack_k): a workgroup takes one sort tile [st0, st1) = two pack tiles,
+// runs the assign step on the 64-event blocks its events lie in (block states from the spine) and keeps k in LDS.
+// No k_map, no k_assign launch.
+template <typename T, typename ET>
+void launch_pack_k(hipStream_t s, const T *planes, const ET *sorted_e, const uint32_t *pix_of, const uint32_t *block_state,
+                   const uint32_t *tile_off, const uint32_t *chain_base, const uint32_t *chain_len, uint64_t *status,
+                   uint64_t *tile_bitoff, uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last,
+                   uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t st0, uint32_t st1, uint32_t epoch,
+                   uint32_t *ticket);
 void launch_join_edges(hipStream_t s, const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint32_t *edge_first,
                        const uint32_t *edge_last, const PackTarget &to, const Geometry &g);
 void launch_concat_planes(hipStream_t s, const uint64_t *plane_base, const uint64_t *plane_carry, const PackTarget &to,

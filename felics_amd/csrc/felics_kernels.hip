@@ -618,6 +618,43 @@ __device__ __forceinline__ void assign_block(const BlockIn &in, const uint32_t v
     if (lane < valid && in.pix != 0xFFFFFFFFu) k_map[in.pix] = (uint8_t)kk;
 }
 
+// The same for the pack stage's own use (k_pack_k): k goes to an LDS array indexed by pixel (pix - pix0), only for
+// the lanes whose events belong to the caller's tile (`mine`); lanes at or behind `nlive` hold no event yet.
+__device__ __forceinline__ void assign_block_lds(const BlockIn &in, const bool mine, const uint32_t nlive, uint8_t *kq, uint32_t pix0) {
+    const uint32_t lane = lane_id();
+    uint32_t S0 = in.sa.x, S1 = in.sa.y, S2 = in.sa.z, S3 = in.sa.w, S4 = in.sb.x, S5 = in.sb.y;
+    uint32_t l01, l23, l45;
+    packed_lengths(in.e, l01, l23, l45);
+    const uint32_t p01 = wave_incl_scan(l01), p23 = wave_incl_scan(l23), p45 = wave_incl_scan(l45);
+    const uint32_t P0 = p01 & 0xFFFFu, P1 = p01 >> 16, P2 = p23 & 0xFFFFu, P3 = p23 >> 16;
+    const uint32_t P4 = p45 & 0xFFFFu, P5 = p45 >> 16;
+    const uint32_t l0 = l01 & 0xFFFFu, l1 = l01 >> 16, l2 = l23 & 0xFFFFu, l3 = l23 >> 16, l4 = l45 & 0xFFFFu,
+                   l5 = l45 >> 16;
+    uint32_t kk = 0, lo = 0;
+    while (true) {
+        const uint32_t T0 = S0 + P0, T1 = S1 + P1, T2 = S2 + P2, T3 = S3 + P3, T4 = S4 + P4, T5 = S5 + P5;
+        const uint32_t mn = min(min(min(T0, T1), min(T2, T3)), min(T4, T5));
+        const uint32_t X0 = T0 - l0, X1 = T1 - l1, X2 = T2 - l2, X3 = T3 - l3, X4 = T4 - l4, X5 = T5 - l5;
+        const uint32_t key = min(min(min((X0 << 3) | 7u, (X1 << 3) | 6u), min((X2 << 3) | 5u, (X3 << 3) | 4u)),
+                                 min((X4 << 3) | 3u, (X5 << 3) | 2u));
+        const uint32_t cand = 7u - (key & 7u);
+        const uint64_t hm = __ballot(lane >= lo && lane < nlive && mn > 1024u);
+        if (hm == 0) {
+            if (lane >= lo) kk = cand;
+            break;
+        }
+        const uint32_t f = (uint32_t)__ffsll((long long)hm) - 1u;
+        if (lane >= lo && lane <= f) kk = cand;
+        const uint32_t f0 = readlane(P0, f), f1 = readlane(P1, f), f2 = readlane(P2, f);
+        const uint32_t f3 = readlane(P3, f), f4 = readlane(P4, f), f5 = readlane(P5, f);
+        S0 = ((S0 + f0) >> 1) - f0; S1 = ((S1 + f1) >> 1) - f1; S2 = ((S2 + f2) >> 1) - f2;
+        S3 = ((S3 + f3) >> 1) - f3; S4 = ((S4 + f4) >> 1) - f4; S5 = ((S5 + f5) >> 1) - f5;
+        lo = f + 1;
+        if (lo >= nlive) break;
+    }
+    if (mine) kq[in.pix - pix0] = (uint8_t)kk;
+}
+
 // Tags are dealt to the waves one by one (tag g belongs to wave g % nwaves): the blocks a spine launch
 // resolved are long runs of consecutive blocks of the long chains, and this way a run is shared by as
 // many waves as it has blocks.  While a block is computed the next block's loads are already in flight.
@@ -717,6 +754,12 @@ __device__ __forceinline__ void stage_span(U *lds, const U *__restrict__ g, int6
 }
 
 template <typename T>
+__device__ __forceinline__ void stage_pixels(TileLDS<T> &t, const T *__restrict__ pl, uint32_t tile_first, uint32_t W, uint32_t npix) {
+    stage_span<T>(t.cur, pl, (int64_t)tile_first - STAGE_LEAD, STAGE_LEAD + PACK_TILE, npix);
+    stage_span<T>(t.up, pl, (int64_t)tile_first - W, PACK_TILE + 16, npix);
+}
+
+template <typename T>
 __device__ __forceinline__ void stage_tile(TileLDS<T> &t, const T *__restrict__ pl, const uint8_t *__restrict__ kpl,
                                            uint32_t tile_first, uint32_t W, uint32_t npix) {
     stage_span<T>(t.cur, pl, (int64_t)tile_first - STAGE_LEAD, STAGE_LEAD + PACK_TILE, npix);
@@ -730,8 +773,8 @@ __device__ __forceinline__ void stage_tile(TileLDS<T> &t, const T *__restrict__ 
 // group itself, the row above from `up`; only the second neighbour of a first-column pixel
 // (two rows up) is fetched from global memory, once per image row.
 template <typename T, typename FR, typename F>
-__device__ __forceinline__ void walk_group(const TileLDS<T> &t, const T *__restrict__ pl, uint32_t first, uint32_t end,
-                                           uint32_t W, FR &&raw, F &&f) {
+__device__ __forceinline__ void walk_group(const TileLDS<T> &t, const uint8_t *kq, const T *__restrict__ pl, uint32_t first,
+                                           uint32_t end, uint32_t W, FR &&raw, F &&f) {
     if (first >= end) return;
     constexpr uint32_t NW = PACK_PER_THREAD * sizeof(T) / 4;  // dwords holding the group's pixels
     const uint32_t off = threadIdx.x * PACK_PER_THREAD;
@@ -744,7 +787,7 @@ __device__ __forceinline__ void walk_group(const TileLDS<T> &t, const T *__restr
         uw[4 * q] = b.x; uw[4 * q + 1] = b.y; uw[4 * q + 2] = b.z; uw[4 * q + 3] = b.w;
     }
     {
-        const uint4 c = *reinterpret_cast<const uint4 *>(t.kq + off);
+        const uint4 c = *reinterpret_cast<const uint4 *>(kq + off);
         kw[0] = c.x; kw[1] = c.y; kw[2] = c.z; kw[3] = c.w;
     }
     int left = (int)t.cur[STAGE_LEAD + off - 1], left2 = (int)t.cur[STAGE_LEAD + off - 2];
@@ -825,7 +868,7 @@ __global__ __launch_bounds__(PACK_THREADS) void k_lengths(const T *__restrict__ 
     const uint32_t first = tile_first + threadIdx.x * PACK_PER_THREAD;
     const uint32_t end = min(tile_first + PACK_TILE, npix);
     uint32_t bits = 0;
-    walk_group(tl, pl, first, end, W, [&](uint32_t, uint32_t) { bits += 32u; },
+    walk_group(tl, tl.kq, pl, first, end, W, [&](uint32_t, uint32_t) { bits += 32u; },
                [&](const PixelClass &pc, uint32_t k) { bits += code_length(pc, k); });
     if (npix == 1 && first == 0) bits += 32;  // 1x1: second raw value is a literal 0 (compression.rs:99-103)
     if (tile == 0 && threadIdx.x == 0 && (plane % planes_per_image) == 0) bits += 8 * 14;  // header
@@ -1007,7 +1050,7 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ pla
                 bw.put(W, 32);
                 bw.put(H, 32);
             }
-            walk_group(tl, pl, first, end, W,
+            walk_group(tl, tl.kq, pl, first, end, W,
                        [&](uint32_t, uint32_t rv) {
                            bw.put(rv, 32);  // write_signed(32, p): sign-extended sample
                            if (npix == 1) bw.put(0u, 32);
@@ -1092,21 +1135,52 @@ struct LocalBits {
     }
 };
 
-// (u8 planes: six waves per SIMD -- 80 VGPRs, 25.6 KB of LDS per workgroup; i16 planes: four, 33.8 KB)
+// The single-pass pack of ONE tile by a workgroup (the body of k_pack_fused and of k_pack_k): see the comment above.
+// kq = the tile's k bytes in LDS; they are staged from k_map unless k_map is null (the caller has put them there).
+struct FusedArgs {
+    uint64_t *status;
+    uint64_t *tile_bitoff;
+    uint32_t *tile_bits;
+    uint64_t *plane_carry;
+    uint32_t *edge_first, *edge_last, *error;
+    PlaneOut po;
+    uint32_t W, H, npix, ntiles, color, depth, epoch;
+    // Tiles are handed out by a ticket counter (zeroed before the launch) in (tile, plane) order instead of by
+    // blockIdx: a tile only ever waits for tiles with smaller tickets, which are held by workgroups that are already
+    // running, whatever else shares the GPU -- also another pack kernel whose workgroups spin in their own look-back
+    // (with blockIdx two such kernels can hold each other's predecessors out of the CUs: the XCDs dispatch their
+    // shares of a grid independently).
+    uint32_t *ticket;
+    uint32_t nplanes;
+};
+struct FusedLDS {
+    uint32_t win[FUSED_WIN_WORDS];
+    uint32_t lbuf[LOCAL_WORDS * PACK_THREADS];
+    uint32_t wsum[PACK_THREADS / 64];
+    uint64_t tile_lo_sh;
+    uint32_t ticket_sh;
+};
+
+// this workgroup's (tile offset in the launch, plane)
+__device__ __forceinline__ void take_ticket(const FusedArgs &fa, FusedLDS &fl, uint32_t &x, uint32_t &plane) {
+    if (threadIdx.x == 0) fl.ticket_sh = atomicAdd(fa.ticket, 1u);
+    __syncthreads();
+    const uint32_t t = fl.ticket_sh;
+    x = t / fa.nplanes;
+    plane = t - x * fa.nplanes;
+}
+
 template <typename T>
-__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_fused(const T *__restrict__ planes, const uint8_t *__restrict__ k_map,
-                                                             uint64_t *__restrict__ status, uint64_t *__restrict__ tile_bitoff,
-                                                             uint32_t *__restrict__ tile_bits, uint64_t *__restrict__ plane_carry,
-                                                             uint32_t *__restrict__ edge_first, uint32_t *__restrict__ edge_last,
-                                                             uint32_t *__restrict__ error, PlaneOut po, uint32_t W, uint32_t H,
-                                                             uint32_t npix, uint32_t ntiles, uint32_t color, uint32_t depth,
-                                                             uint32_t tile_begin, uint32_t epoch) {
-    __shared__ TileLDS<T> tl;
-    __shared__ uint32_t win[FUSED_WIN_WORDS];
-    __shared__ uint32_t lbuf[LOCAL_WORDS * PACK_THREADS];
-    __shared__ uint32_t wsum[PACK_THREADS / 64];
-    __shared__ uint64_t tile_lo_sh;
-    const uint32_t tile = tile_begin + blockIdx.x, plane = blockIdx.y;
+__device__ __forceinline__ void pack_tile_fused(TileLDS<T> &tl, const uint8_t *kq, FusedLDS &fl, const T *__restrict__ planes,
+                                                const uint8_t *__restrict__ k_map, const FusedArgs &fa, uint32_t tile, uint32_t plane) {
+    uint32_t (&win)[FUSED_WIN_WORDS] = fl.win;
+    uint32_t (&lbuf)[LOCAL_WORDS * PACK_THREADS] = fl.lbuf;
+    uint32_t (&wsum)[PACK_THREADS / 64] = fl.wsum;
+    uint64_t &tile_lo_sh = fl.tile_lo_sh;
+    uint64_t *status = fa.status, *tile_bitoff = fa.tile_bitoff, *plane_carry = fa.plane_carry;
+    uint32_t *tile_bits = fa.tile_bits, *edge_first = fa.edge_first, *edge_last = fa.edge_last, *error = fa.error;
+    const PlaneOut &po = fa.po;
+    const uint32_t W = fa.W, H = fa.H, npix = fa.npix, ntiles = fa.ntiles, color = fa.color, depth = fa.depth, epoch = fa.epoch;
     const bool first_plane = plane % po.planes_per_image == 0;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const T *pl = planes + (uint64_t)plane * npix;
@@ -1116,7 +1190,10 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch
     const bool has_header = tile == 0 && threadIdx.x == 0 && first_plane;
     uint64_t *my_status = status + (uint64_t)plane * ntiles + tile;
 
-    stage_tile(tl, pl, k_map + (uint64_t)plane * npix, tile_first, W, npix);
+    if (k_map)
+        stage_tile(tl, pl, k_map + (uint64_t)plane * npix, tile_first, W, npix);
+    else
+        stage_pixels(tl, pl, tile_first, W, npix);  // (k is in LDS already)
     __syncthreads();
 
     // ---- phase 1: this thread's bit string
@@ -1129,7 +1206,7 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch
             lb.put(W, 32);
             lb.put(H, 32);
         }
-        walk_group(tl, pl, first, end, W,
+        walk_group(tl, kq, pl, first, end, W,
                    [&](uint32_t, uint32_t rv) {
                        lb.put(rv, 32);  // write_signed(32, p): sign-extended sample
                        if (npix == 1) lb.put(0u, 32);
@@ -1246,7 +1323,7 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch
                     bw.put(W, 32);
                     bw.put(H, 32);
                 }
-                walk_group(tl, pl, first, end, W,
+                walk_group(tl, kq, pl, first, end, W,
                            [&](uint32_t, uint32_t rv) {
                                bw.put(rv, 32);
                                if (npix == 1) bw.put(0u, 32);
@@ -1268,6 +1345,80 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch
                 out_words[aw] = __builtin_bswap32(v);
             }
         }
+    }
+}
+
+// (u8 planes: six waves per SIMD -- 80 VGPRs, 25.6 KB of LDS per workgroup; i16 planes: four, 33.8 KB)
+template <typename T>
+__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_fused(const T *__restrict__ planes, const uint8_t *__restrict__ k_map,
+                                                             FusedArgs fa, uint32_t tile_begin) {
+    __shared__ TileLDS<T> tl;
+    __shared__ FusedLDS fl;
+    uint32_t x, plane;
+    take_ticket(fa, fl, x, plane);
+    pack_tile_fused<T>(tl, tl.kq, fl, planes, k_map, fa, tile_begin + x, plane);
+}
+
+// ------------------------------------------------------------------------------------------
+// pack with k computed in place (k_pack_k): a workgroup takes one tile (sort tile = pack tile).  Every context's
+// events of a sort tile are one run of slots in the context's chain (tile_off[t][c] .. tile_off[t + 1][c]); the
+// workgroup runs assign_block on exactly the 64-event blocks that overlap those runs (the blocks' start states
+// come from the spine) and keeps k in an LDS array indexed by pixel, then packs the tile.  There is no k per
+// pixel in HBM, and no pass that scatters one byte per event across it.
+// ------------------------------------------------------------------------------------------
+
+struct KSources {
+    const void *sorted_e;
+    const uint32_t *pix_of, *block_state, *tile_off, *chain_base, *chain_len;
+    uint32_t sort_ntiles;
+};
+
+template <typename T, typename ET>
+__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_k(const T *__restrict__ planes, KSources ks, FusedArgs fa,
+                                                                                               uint32_t sort_tile_begin, uint32_t pack_tile_end) {
+    __shared__ TileLDS<T> tl;
+    __shared__ FusedLDS fl;
+    static_assert(SORT_TILE == PACK_TILE, "one workgroup = one sort tile = one pack tile (one look-back per workgroup)");
+    uint8_t *kq2 = tl.kq;
+    uint32_t x, plane;
+    take_ticket(fa, fl, x, plane);
+    const uint32_t st = sort_tile_begin + x;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr uint32_t NWV = PACK_THREADS / 64;
+    // ---- k of this sort tile's events.  Wave w takes the contexts w, w + 4, ...
+    {
+        const uint32_t *off0 = ks.tile_off + ((uint64_t)plane * ks.sort_ntiles + st) * NCTX;
+        const bool last_tile = st + 1 == ks.sort_ntiles;
+        const uint32_t *off1 = last_tile ? ks.chain_len + (uint64_t)plane * NCTX : off0 + NCTX;
+        const uint32_t *cb = ks.chain_base + (uint64_t)plane * NCTX;
+        const ET *sorted_e = reinterpret_cast<const ET *>(ks.sorted_e);
+        const uint4 *stt = reinterpret_cast<const uint4 *>(ks.block_state);
+        const uint32_t pix0 = plane * fa.npix + st * SORT_TILE;  // pix_of holds plane * npix + i
+        for (uint32_t c0 = 0; c0 < NCTX; c0 += 64 * NWV) {
+            const uint32_t c = c0 + lane * NWV + wave;
+            const uint32_t a = off0[c], b = off1[c];
+            const uint32_t base = cb[c];
+            uint64_t todo = __ballot(b > a);
+            while (todo) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint32_t sa = readlane(a, l) + readlane(base, l), sb = readlane(b, l) + readlane(base, l);  // slots [sa, sb)
+                for (uint32_t gb = sa >> 6; gb <= (sb - 1) >> 6; gb++) {
+                    BlockIn in = load_block<ET>(stt, sorted_e, ks.pix_of, gb);
+                    const uint32_t slot = gb * 64u + lane;
+                    if (slot >= sb) in.e = 0;  // not scattered yet (a later tile's events): whatever lies there is not an event
+                    assign_block_lds(in, slot >= sa && slot < sb, min(64u, sb - gb * 64u), kq2, pix0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t half = 0; half < SORT_TILE / PACK_TILE; half++) {
+        const uint32_t tile = st * (SORT_TILE / PACK_TILE) + half;
+        if (tile >= pack_tile_end) break;
+        pack_tile_fused<T>(tl, kq2 + half * PACK_TILE, fl, planes, nullptr, fa, tile, plane);
+        __syncthreads();
     }
 }
 
@@ -1491,19 +1642,42 @@ template void launch_pack<int32_t>(hipStream_t, const int32_t *, const uint8_t *
 template <typename T>
 void launch_pack_fused(hipStream_t s, const T *planes, const uint8_t *k_map, uint64_t *status, uint64_t *tile_bitoff,
                        uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last,
-                       uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t t0, uint32_t t1, uint32_t epoch) {
+                       uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t t0, uint32_t t1, uint32_t epoch,
+                       uint32_t *ticket) {
     if (t1 <= t0) return;
-    const PlaneOut po{to.out, to.slot_stride, to.scratch, to.plane_slot, g.planes_per_image};
-    FELICS_LAUNCH((k_pack_fused<T>), dim3(t1 - t0, g.nplanes), dim3(PACK_THREADS), s, planes, k_map, status,
-                       tile_bitoff, tile_bits, plane_carry, edge_first, edge_last, error, po, g.W, g.H, g.npix,
-                       g.pack_tiles, g.color, g.depth, t0, epoch);
+    const FusedArgs fa{status, tile_bitoff, tile_bits, plane_carry, edge_first, edge_last, error,
+                       PlaneOut{to.out, to.slot_stride, to.scratch, to.plane_slot, g.planes_per_image},
+                       g.W, g.H, g.npix, g.pack_tiles, g.color, g.depth, epoch, ticket, g.nplanes};
+    FELICS_LAUNCH((k_pack_fused<T>), dim3(t1 - t0, g.nplanes), dim3(PACK_THREADS), s, planes, k_map, fa, t0);
 }
 template void launch_pack_fused<uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, uint64_t *, uint64_t *, uint32_t *,
                                          uint64_t *, uint32_t *, uint32_t *, uint32_t *, const PackTarget &,
-                                         const Geometry &, uint32_t, uint32_t, uint32_t);
+                                         const Geometry &, uint32_t, uint32_t, uint32_t, uint32_t *);
 template void launch_pack_fused<int16_t>(hipStream_t, const int16_t *, const uint8_t *, uint64_t *, uint64_t *, uint32_t *,
                                          uint64_t *, uint32_t *, uint32_t *, uint32_t *, const PackTarget &,
-                                         const Geometry &, uint32_t, uint32_t, uint32_t);
+                                         const Geometry &, uint32_t, uint32_t, uint32_t, uint32_t *);
+
+template <typename T, typename ET>
+void launch_pack_k(hipStream_t s, const T *planes, const ET *sorted_e, const uint32_t *pix_of, const uint32_t *block_state,
+                   const uint32_t *tile_off, const uint32_t *chain_base, const uint32_t *chain_len, uint64_t *status,
+                   uint64_t *tile_bitoff, uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last,
+                   uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t st0, uint32_t st1, uint32_t epoch,
+                   uint32_t *ticket) {
+    if (st1 <= st0) return;
+    const FusedArgs fa{status, tile_bitoff, tile_bits, plane_carry, edge_first, edge_last, error,
+                       PlaneOut{to.out, to.slot_stride, to.scratch, to.plane_slot, g.planes_per_image},
+                       g.W, g.H, g.npix, g.pack_tiles, g.color, g.depth, epoch, ticket, g.nplanes};
+    const KSources ks{sorted_e, pix_of, block_state, tile_off, chain_base, chain_len, g.sort_tiles};
+    FELICS_LAUNCH((k_pack_k<T, ET>), dim3(st1 - st0, g.nplanes), dim3(PACK_THREADS), s, planes, ks, fa, st0, g.pack_tiles);
+}
+template void launch_pack_k<uint8_t, uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, const uint32_t *, const uint32_t *,
+                                              const uint32_t *, const uint32_t *, const uint32_t *, uint64_t *, uint64_t *, uint32_t *,
+                                              uint64_t *, uint32_t *, uint32_t *, uint32_t *, const PackTarget &, const Geometry &,
+                                              uint32_t, uint32_t, uint32_t, uint32_t *);
+template void launch_pack_k<int16_t, uint16_t>(hipStream_t, const int16_t *, const uint16_t *, const uint32_t *, const uint32_t *,
+                                               const uint32_t *, const uint32_t *, const uint32_t *, uint64_t *, uint64_t *, uint32_t *,
+                                               uint64_t *, uint32_t *, uint32_t *, uint32_t *, const PackTarget &, const Geometry &,
+                                               uint32_t, uint32_t, uint32_t, uint32_t *);
 
 void launch_join_edges_tiles(hipStream_t s, const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint32_t *edge_first,
                              const uint32_t *edge_last, const PackTarget &to, const Geometry &g, uint32_t ntiles) {

@@ -277,7 +277,9 @@ def test_pack_variants(oracle):
 
     frames = [synth.gray8(1920, 1080, f, "S1") for f in range(16)] + [synth.gray8(1920, 1080, 3, "S2")]
     want = [oracle.compress(f) for f in frames]
-    for env in ({}, {"FELICS_TWO_PASS": "1"}, {"FELICS_TEST_LOOKBACK_FAIL": "1"}):
+    # default: k computed inside the single-pass pack (k_pack_k); FELICS_ASSIGN=kernel: separate k_assign kernel + k_map
+    for env in ({}, {"FELICS_ASSIGN": "kernel"}, {"FELICS_TWO_PASS": "1"}, {"FELICS_TEST_LOOKBACK_FAIL": "1"},
+                {"FELICS_ASSIGN": "kernel", "FELICS_TEST_LOOKBACK_FAIL": "1"}, {"FELICS_OWN_TAILS": "1"}):
         os.environ.update(env)
         os.environ["FELICS_POISON"] = "1"
         try:
@@ -288,6 +290,8 @@ def test_pack_variants(oracle):
         try:
             assert e.compress_batch(frames) == want, env
             assert e.compress_batch(frames[:3]) == want[:3], env  # the same context again (after a fallback)
+            rgb = [synth.rgb8(640, 360, f) for f in range(3)]
+            assert e.compress_batch(rgb) == [oracle.compress(f) for f in rgb], env
         finally:
             e.close()
 

@@ -322,6 +322,16 @@ def main():
         # durations of kernel k's launches in one step (HIP events on the stream each launch runs on).
         launches = max(1, enc.stage_launches().get(dom, 1)) if dom else 1
         roofline = None
+
+        def kernel_of(stage):  # the kernel a stage name stands for on the path that ran
+            if stage == "pack":
+                if args.depth16:
+                    return "k_pack"
+                return "k_pack_fused" if os.environ.get("FELICS_ASSIGN") == "kernel" else "k_pack_k"
+            if stage == "offsets":
+                return "k_tile_offsets"
+            return "k_" + stage
+
         if dom and stage_ms[dom] > 0:
             per_launch_ms = stage_ms[dom] / launches
             per_launch_bytes = alg_bytes / launches
@@ -337,13 +347,13 @@ def main():
 
                 tj = json.load(open(tpath))
                 if tj.get("_source_sha256") == fbuild.source_hash():
-                    t = tj.get("k_" + dom, {}).get("hbm_bytes_per_step")
+                    t = tj.get(kernel_of(dom), {}).get("hbm_bytes_per_step")
                     traffic = int(t / launches) if t else None
                     insts = tj.get("_valu_wave_insts_per_step")
                     if insts:  # wave64 VALU instructions per step against 1024 SIMDs x 2.4 GHz / 2 cycles per instruction
                         valu = {"wave_insts_per_step": int(insts), "issue_peak_per_s": 1.2288e12,
                                 "frac_of_issue_peak": round(insts / 1.2288e12 / (ms_per_step * 1e-3), 4)}
-            roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            roofline = {"bound": "hbm", "kernel": kernel_of(dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(per_launch_ms, 4),
                         "launches_per_step": launches, "valu": valu}
@@ -353,7 +363,7 @@ def main():
         for k, v in stage_ms.items():
             n = max(1, enc.stage_launches().get(k, 1))
             if v > 0:
-                per_stage["k_" + k] = {"avg_launch_ms": round(v / n, 4), "launches_per_step": n,
+                per_stage[kernel_of(k)] = {"avg_launch_ms": round(v / n, 4), "launches_per_step": n,
                                        "achieved_GBs": round(alg_bytes / n / (v / n * 1e-3) / 1e9, 2)}
         pipeline_gbs = alg_bytes / (ms_per_step * 1e-3) / 1e9
         cpu1 = cpum = None
@@ -383,7 +393,7 @@ def main():
                          "per_stage": per_stage,
                          "submission": "blocking calls" if args.synchronous else "%d batches in flight (submit ahead, wait in order)" % depth_q,
                          "ms_per_step_blocking_calls": None if sync_ms is None else round(sync_ms, 3),
-                         "note": "the stages follow each other slice by slice on four HIP streams; launches overlap, so the sums exceed ms_per_step"},
+                         "note": "the stages follow each other slice by slice on HIP streams of their own; launches overlap, so the sums exceed ms_per_step"},
             "parity": {"frames_byte_compared_with_oracle": checked, "streams_digest_checked_after_timed_steps": F,
                        "compressed_bytes_per_step_rank0": total_bytes,
                        "bits_per_pixel": round(total_bytes * 8 / (F * npix), 4)},

@@ -191,24 +191,28 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
             }
             __builtin_amdgcn_wave_barrier();
         };
+        // The pixel to the left and the one before it stay in registers; the sample above the NEXT pixel is fetched
+        // while this one is decoded, so its LDS latency is off the serial path.
+        int left = 0, left2 = 0, up_next = 0;
         for (uint64_t i = 0; i < npix; i++) {
             int pv;
+            const int above = up_next;
+            if (y > 0 && x + 1 < W) up_next = prev[x + 1];
             if (i < 2) {
                 pv = i == 0 ? p0 : p1;
-                if (npix == 1 && i == 0) pv = p0;
             } else {
                 int v1, v2;  // misc.rs:6-24
                 if (x > 0 && y > 0) {
-                    v1 = cur[x - 1];
-                    v2 = prev[x];
+                    v1 = left;
+                    v2 = above;
                 } else if (y == 0) {
-                    v1 = cur[x - 1];
-                    v2 = cur[x - 2];
+                    v1 = left;
+                    v2 = left2;
                 } else if (y >= 2) {  // first column: above and two rows up (the row `cur` still holds: it was row y - 2)
-                    v1 = prev[0];
+                    v1 = above;
                     v2 = cur[0];
                 } else {  // pixel (0,1): above and above-right
-                    v1 = prev[0];
+                    v1 = above;
                     v2 = prev[1];
                 }
                 const int hi = max(v1, v2), lo = min(v1, v2);
@@ -223,11 +227,10 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
                     if (rot >= n) rot -= n;
                     pv = lo + (int)rot;
                 } else {
-                    const bool above = br.get(1) != 0;
-                    uint32_t *row = table + ctx * 6;
-                    uint32_t S[6];
-#pragma unroll
-                    for (uint32_t k = 0; k < 6; k++) S[k] = row[k];
+                    const bool above_flag = br.get(1) != 0;
+                    uint64_t *row = reinterpret_cast<uint64_t *>(table + ctx * 6);  // 24-byte rows: 8-byte aligned
+                    const uint64_t r01 = row[0], r23 = row[1], r45 = row[2];     // one LDS round trip for the row
+                    uint32_t S[6] = {(uint32_t)r01, (uint32_t)(r01 >> 32), (uint32_t)r23, (uint32_t)(r23 >> 32), (uint32_t)r45, (uint32_t)(r45 >> 32)};
                     // get_k: smallest counter, ties to the largest k (parameter_selection.rs:71-85)
                     const uint32_t key = min(min(min((S[0] << 3) | 7u, (S[1] << 3) | 6u), min((S[2] << 3) | 5u, (S[3] << 3) | 4u)),
                                              min((S[4] << 3) | 3u, (S[5] << 3) | 2u));
@@ -251,10 +254,11 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
                     }
                     const uint32_t hsh = mn > 1024u ? 1u : 0u;
                     if (lane == 0) {
-#pragma unroll
-                        for (uint32_t kk = 0; kk < 6; kk++) row[kk] = S[kk] >> hsh;
+                        row[0] = (uint64_t)(S[0] >> hsh) | ((uint64_t)(S[1] >> hsh) << 32);
+                        row[1] = (uint64_t)(S[2] >> hsh) | ((uint64_t)(S[3] >> hsh) << 32);
+                        row[2] = (uint64_t)(S[4] >> hsh) | ((uint64_t)(S[5] >> hsh) << 32);
                     }
-                    pv = above ? hi + (int)e + 1 : lo - (int)e - 1;
+                    pv = above_flag ? hi + (int)e + 1 : lo - (int)e - 1;
                 }
                 if (br.failed) {
                     rc = FELICS_E_IO;
@@ -266,14 +270,16 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
                 break;
             }
             if (lane == 0) cur[x] = (int16_t)pv;
-            __builtin_amdgcn_wave_barrier();
+            left2 = left;
+            left = pv;
             if (++x == W) {
-                flush_row(y, cur);
+                flush_row(y, cur);  // (its wave barriers also order the row's writes before the next row reads them)
                 x = 0;
                 y++;
                 int16_t *t = cur;
                 cur = prev;
                 prev = t;
+                up_next = prev[0];
             }
         }
     }

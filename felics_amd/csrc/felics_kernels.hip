@@ -511,7 +511,9 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
                 const uint32_t mn = min(min(min(S0 + P0, S1 + P1), min(S2 + P2, S3 + P3)), min(S4 + P4, S5 + P5));
                 const uint64_t hm = __ballot(lane >= lo && mn > 1024u);
                 // (the block-level test said a halving exists, and after a halving the loop is only
-                // re-entered when the end state says there is another: hm is never empty here)
+                // re-entered when the end state says there is another: hm is never empty here -- but a wave
+                // that spins forever on a broken invariant takes the whole GPU with it, so it is checked)
+                if (hm == 0) break;
                 const uint32_t f = (uint32_t)__ffsll((long long)hm) - 1u;
                 // S <- ((S + P(f)) >> 1) - P(f): later lanes add their own P(t) >= P(f) back (mod 2^32).
                 // Done on the state vector itself: lane l picks P_{l & 7}(f) out of the three packed scans.

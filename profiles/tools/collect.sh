@@ -1,23 +1,31 @@
 #!/bin/bash
-# Runs ON THE GPU BOX from the repository root:  bash profiles/tools/collect.sh r01_final
-# 1. bench.py line (with cpu_baseline)            -> gpurun_out/<tag>/bench.json
-# 2. rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 0 --no-blocking-extra` (13 steps, 12 of them
-#    through the submission queue like the timed ones) -> gpurun_out/<tag>/kernel_stats.csv (felics:: kernels only)
-# 3. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, no trace domains) of
-#    `bench.py --steps 1 --warmup 0 --synchronous` -> gpurun_out/<tag>/traffic.json (profiles/tools/summarize.py)
-# Copy what should be judged from gpurun_out/<tag>/ into profiles/<round>/ afterwards.
+# Runs ON THE GPU BOX from the repository root:  bash profiles/tools/collect.sh <tag>
+# 1. the default bench line (cpu_baseline, side configs, decode leg)      -> gpurun_out/<tag>/bench.json
+# 2. rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 0 --no-blocking-extra` (timed steps through the
+#    submission queue, as in 1.)                                           -> gpurun_out/<tag>/kernel_stats.csv
+# 3. rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE, --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY (three
+#    separate passes, counters only: no trace domains) of ONE checked + ONE timed blocking step
+#                                                                          -> gpurun_out/<tag>/traffic.json
+# Copy what should be judged from gpurun_out/<tag>/ into profiles/<round>/ (and traffic.json to profiles/) afterwards.
 set -eo pipefail
 tag=${1:-run}
 R=$(pwd)
 O=$R/gpurun_out/$tag
 mkdir -p "$O"
 export TMPDIR=/tmp
-timeout -k 10 300 python3 bench.py > "$O/bench.json" 2> "$O/bench.err"
+echo "[collect] bench line"
+timeout -k 10 400 python3 bench.py > "$O/bench.json" 2> "$O/bench.err" || { tail -5 "$O/bench.err"; exit 1; }
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 "$R/bench.py" --steps 10 --warmup 0 --cpu-seconds 0 --no-blocking-extra > "$O/kt.log" 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -- python3 "$R/bench.py" --steps 1 --warmup 0 --cpu-seconds 0 --synchronous > "$O/fetch.log" 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write" -- python3 "$R/bench.py" --steps 1 --warmup 0 --cpu-seconds 0 --synchronous > "$O/write.log" 2>&1
+PMC_ARGS="--steps 1 --warmup 0 --synchronous --no-blocking-extra --no-side-configs --no-decode-leg --cpu-seconds 0"
+echo "[collect] kernel trace"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 "$R/bench.py" --steps 10 --warmup 0 --cpu-seconds 0 --no-blocking-extra --no-side-configs --no-decode-leg > "$O/kt.log" 2>&1 || { tail -5 "$O/kt.log"; exit 1; }
+echo "[collect] FETCH_SIZE"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -- python3 "$R/bench.py" $PMC_ARGS > "$O/fetch.log" 2>&1 || { tail -5 "$O/fetch.log"; exit 1; }
+echo "[collect] WRITE_SIZE"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write" -- python3 "$R/bench.py" $PMC_ARGS > "$O/write.log" 2>&1 || { tail -5 "$O/write.log"; exit 1; }
+echo "[collect] SQ counters"
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$O/sq" -- python3 "$R/bench.py" $PMC_ARGS > "$O/sq.log" 2>&1 || { tail -5 "$O/sq.log"; exit 1; }
 cd "$R"
 python3 profiles/tools/summarize.py "$O"
-rm -rf "$O/kt" "$O/fetch" "$O/write"
+rm -rf "$O/kt" "$O/fetch" "$O/write" "$O/sq"
 ls -la "$O"

@@ -93,6 +93,7 @@ struct felics_ctx {
     bool pack_k = true;         // the single-pass pack computes k itself, in LDS (k_pack_k): no k_assign launches, no k per pixel in HBM.
                                 // FELICS_ASSIGN=kernel selects the separate k_assign kernel + k_map again
     bool two_pass = false;      // FELICS_TWO_PASS=1, or a look-back of the single-pass pack gave up once: lengths + pack kernels
+    bool test_timeout = false;  // FELICS_TEST_TIMEOUT=1: every wait for the GPU reports a time-out (tests of the failed state)
     bool test_stripe_fail = false; // FELICS_TEST_STRIPE_FAIL=1: pretend the first fused-kernel submission gave up (tests)
     bool test_lookback = false; // FELICS_TEST_LOOKBACK_FAIL=1: pretend the first single-pass submission gave up (tests)
     bool poison = false;        // FELICS_POISON=1: overwrite the workspace before every sub-batch (tests)
@@ -131,6 +132,12 @@ int hip_fail(felics_ctx *ctx, hipError_t e, const char *what) {
 // (FELICS_E_HIP, "timed out"), not as a caller that hangs.
 int wait_event(felics_ctx *ctx, hipEvent_t ev, const char *what) {
     const auto t0 = std::chrono::steady_clock::now();
+    if (ctx->test_timeout) {  // FELICS_TEST_TIMEOUT=1 (tests): behave as if the GPU did not answer in time
+        ctx->err = std::string(what) + ": timed out waiting for the GPU; the context is unusable from here on";
+        ctx->failed = true;
+        ctx->stats.failed = 1;
+        return FELICS_E_HIP;
+    }
     for (uint32_t spins = 0;; spins++) {
         const hipError_t e = hipEventQuery(ev);
         if (e == hipSuccess) return FELICS_OK;
@@ -905,6 +912,7 @@ int felics_ctx_create(int device, felics_ctx **out) {
     ctx->test_lookback = getenv("FELICS_TEST_LOOKBACK_FAIL") != nullptr;
     if (const char *e = getenv("FELICS_ASSIGN")) ctx->pack_k = strcmp(e, "kernel") != 0;
     ctx->test_stripe_fail = getenv("FELICS_TEST_STRIPE_FAIL") != nullptr;
+    ctx->test_timeout = getenv("FELICS_TEST_TIMEOUT") != nullptr;
     if (const char *e = getenv("FELICS_PIPELINE")) ctx->stripe = strcmp(e, "stripe") == 0;
     {
         int cus = 0;

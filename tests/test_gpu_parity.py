@@ -485,6 +485,37 @@ def test_two_submissions_in_flight(enc, oracle):
     assert enc.compress(batches[0][0][0]) == oracle.compress(batches[0][0][0])
 
 
+def test_timeout_leaves_a_failed_context(oracle):
+    """A wait for the GPU that times out (forced here) must not leave a context that looks idle while its kernels may
+    still run: the call fails with FELICS_E_HIP, so does every later call, the lane stays busy, stats say `failed`,
+    and destroying the context does not touch the device objects.  A fresh context works."""
+    import felics_amd
+    import torch
+    from felics_amd import synth
+
+    frames = [synth.gray8(640, 480, f, "S1") for f in range(3)]
+    os.environ["FELICS_TEST_TIMEOUT"] = "1"
+    try:
+        e = felics_amd.Encoder(0)
+    finally:
+        del os.environ["FELICS_TEST_TIMEOUT"]
+    with pytest.raises(felics_amd.FelicsError) as ei:
+        e.compress_batch(frames)
+    assert ei.value.code == -9 and "timed out" in str(ei.value)
+    assert e.stats()["failed"] == 1
+    with pytest.raises(felics_amd.FelicsError) as ei:
+        e.compress(frames[0])
+    assert ei.value.code == -9
+    d_in = torch.from_numpy(np.stack(frames)).cuda()
+    d_out = torch.zeros(3 * 640 * 480 * 2, dtype=torch.uint8, device="cuda")
+    with pytest.raises(felics_amd.FelicsError):
+        e.submit_batch_device(d_in.data_ptr(), 3, 640, 480, 0, 0, d_out.data_ptr(), d_out.numel())
+    torch.cuda.synchronize()  # (the kernels of the "timed-out" call do finish here; the context cannot know that)
+    e.close()
+    with felics_amd.Encoder(0) as e2:
+        assert e2.compress_batch(frames) == [oracle.compress(f) for f in frames]
+
+
 def test_errors(enc):
     import felics_amd
 

@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-blocking-extra", action="store_true",
                     help="skip the three extra blocking-call steps after the timed region (rocprofv3 runs: keeps the kernel averages those of the timed steps)")
     ap.add_argument("--no-side-configs", action="store_true", help="skip the short config 2 / config 4 legs of the default run")
+    ap.add_argument("--no-stage-timing", action="store_true", help="leave the library's per-launch event timing off during the timed steps (roofline is then null)")
     ap.add_argument("--no-decode-leg", action="store_true", help="skip the decode measurement (GPU decoder next to the host decoder) of the default run")
     args = ap.parse_args()
     if args.config in (4, 5):
@@ -198,7 +199,7 @@ def main():
         subs = [submit(i) for i in range(depth_q)]
         for sub in subs:
             enc.wait_batch(sub)
-    enc.set_profiling(True)
+    enc.set_profiling(not args.no_stage_timing)
     stage_acc = {}
 
     def finish(sub):  # felics_wait_batch: the batch is complete in HBM when this returns
@@ -209,6 +210,7 @@ def main():
     # The K timed steps go through the two-deep submission queue a streaming caller would use: step i + 1 is
     # queued before step i is waited for, so the GPU classifies / scatters the next batch while it packs the
     # last slices of this one.  Every step runs in full and is complete inside the timed region.
+    host_submit_s = 0.0  # host time inside felics_submit_batch_device (queueing a step's launches)
     group.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -222,7 +224,9 @@ def main():
         for i in range(args.steps):
             if len(inflight) == depth_q:
                 finish(inflight.pop(0))
+            ts = time.perf_counter()
             inflight.append(submit(i))
+            host_submit_s += time.perf_counter() - ts
         while inflight:
             finish(inflight.pop(0))
     torch.cuda.synchronize()
@@ -393,6 +397,7 @@ def main():
                          "per_stage": per_stage,
                          "submission": "blocking calls" if args.synchronous else "%d batches in flight (submit ahead, wait in order)" % depth_q,
                          "ms_per_step_blocking_calls": None if sync_ms is None else round(sync_ms, 3),
+                         "host_ms_per_submit": round(host_submit_s / steps * 1e3, 3),
                          "note": "the stages follow each other slice by slice on HIP streams of their own; launches overlap, so the sums exceed ms_per_step"},
             "parity": {"frames_byte_compared_with_oracle": checked, "streams_digest_checked_after_timed_steps": F,
                        "compressed_bytes_per_step_rank0": total_bytes,

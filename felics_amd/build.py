@@ -47,7 +47,11 @@ def build(force=False, quiet=True):
 
 
 def ensure_lib():
-    """Path of libfelics.so, building it only if it is missing (the GPU box ships it prebuilt)."""
+    """Path of libfelics.so, building it only if it is missing (the GPU box ships it prebuilt).
+    FELICS_LIB_PATH names another build of the library (A/B measurements of two builds on one box)."""
+    alt = os.environ.get("FELICS_LIB_PATH")
+    if alt:
+        return alt
     if not os.path.exists(LIB):
         build()
     return LIB

@@ -810,21 +810,23 @@ __device__ __forceinline__ void walk_group(const TileLDS<T> &t, const uint8_t *k
             if (i < end && i >= 2) {
                 const uint32_t k = (kw[0] >> (8u * j)) & 0xFFu;
                 const int above = sample_at(uw, j, T());
-                int v1 = left, v2 = above;  // interior: left and above
-                if (xy.y == 0) {
-                    v2 = left2;  // first row: the two pixels to the left
-                } else if (xy.x == 0) {
-                    v1 = above;  // first column: above and ...
-                    if (xy.y >= 2)
-                        v2 = (int)pl[i - 2 * W];  // ... two rows up,
-                    else                          // or above-right for pixel (0,1)
-                        v2 = j < 3 ? sample_at(uw, (j + 1) & 3u, T()) : sample_at(&un, 0, T());
-                }
+                // the neighbour rule (misc.rs:6-24) with selects instead of branches: interior = left and above; first row =
+                // the two pixels to the left; first column = above and two rows up (above-right for pixel (0,1)).  Only the
+                // two-rows-up sample needs a branch: it is the one value that is not in registers.
+                const bool row0 = xy.y == 0, col0 = xy.x == 0 && !row0;
+                const int v1 = col0 ? above : left;
+                int v2 = row0 ? left2 : above;
+                if (col0) v2 = xy.y >= 2 ? (int)pl[i - 2 * W] : (j < 3 ? sample_at(uw, (j + 1) & 3u, T()) : sample_at(&un, 0, T()));
                 const int H = max(v1, v2), L = min(v1, v2);
+                const int d = p - L, ctx = H - L;  // in range: 0 <= d <= ctx
+                const bool below = d < 0, over = d > ctx;
                 PixelClass pc;
-                pc.ctx = (uint32_t)(H - L);
-                pc.cls = p < L ? CLS_BELOW : (p > H ? CLS_ABOVE : CLS_IN);
-                pc.val = p < L ? (uint32_t)(L - p - 1) : (p > H ? (uint32_t)(p - H - 1) : (uint32_t)(p - L));
+                pc.ctx = (uint32_t)ctx;
+                pc.cls = (below ? (uint32_t)CLS_BELOW : 0u) | (over ? (uint32_t)CLS_ABOVE : 0u);
+                // L - p - 1 = ~d ; p - H - 1 = d - ctx - 1 ; p - L = d: all three computed, two selects
+                uint32_t val = below ? (uint32_t)~d : (uint32_t)d;
+                val = over ? (uint32_t)(d - ctx - 1) : val;
+                pc.val = val;
                 f(pc, k);
             }
             left2 = left;
@@ -1113,12 +1115,14 @@ struct LocalBits {
         acc |= (uint64_t)v << (64u - fill - n);
         fill += n;
         total += n;
-        if (fill >= 32) {
-            if (word < LOCAL_WORDS) buf[word * PACK_THREADS] = (uint32_t)(acc >> 32);
-            acc <<= 32;
-            fill -= 32;
-            word++;
-        }
+        // The word being filled is stored every time (it is stored for good the time it is complete) and the step to the
+        // next word is arithmetic: a branch here is taken by a few lanes at nearly every pixel, so the whole wave would pay
+        // for it at nearly every pixel.
+        if (word < LOCAL_WORDS) buf[word * PACK_THREADS] = (uint32_t)(acc >> 32);
+        const uint32_t adv = fill >> 5;  // 0 or 1: fill < 64 here
+        acc <<= adv << 5;
+        fill &= 31u;
+        word += adv;
     }
     __device__ __forceinline__ void put_ones(uint32_t q) {
         while (q >= 32 && word < LOCAL_WORDS) {

@@ -76,18 +76,33 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, 
     return off + inc - v;
 }
 
-// thread t of tile (blockIdx.x, plane blockIdx.y) owns the 16 consecutive samples first .. first + 15
+// thread t of tile (blockIdx.x, plane blockIdx.y) owns the 16 consecutive samples first .. first + 15: f(j, i, pc) for
+// every event among them.  Samples strictly inside the image (left and above neighbours, misc.rs:6-24) come from two
+// vector loads; a group that touches the first row, the first column or the end of the plane takes the general rule.
 template <typename T, typename F>
 __device__ __forceinline__ void for_my_events(const T *__restrict__ pl, uint32_t W, uint32_t npix, F &&f) {
     const uint32_t first = blockIdx.x * WT + threadIdx.x * 16u;
     if (first >= npix) return;
     Coord xy;
     xy.set(first, W);
+    if (xy.y > 0 && xy.x > 0 && xy.x + 16u <= W && first + 16u <= npix) {
+        T cur[16], up[16];
+        __builtin_memcpy(cur, pl + first, sizeof cur);
+        __builtin_memcpy(up, pl + first - W, sizeof up);
+        int left = (int)pl[first - 1];
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; j++) {
+            const PixelClass pc = classify_values((int)cur[j], left, (int)up[j]);
+            if (pc.cls != CLS_IN) f(j, first + j, pc);
+            left = (int)cur[j];
+        }
+        return;
+    }
     for (uint32_t j = 0; j < 16u && first + j < npix; j++) {
         const uint32_t i = first + j;
         if (i >= 2) {
             const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
-            if (pc.cls != CLS_IN) f(i, pc);
+            if (pc.cls != CLS_IN) f(j, i, pc);
         }
         xy.advance(1, W);
     }
@@ -99,7 +114,7 @@ __global__ __launch_bounds__(WTHREADS) void k_wide_count(const T *__restrict__ p
     __shared__ uint32_t wsum[WTHREADS / 64];
     const T *pl = planes + (uint64_t)blockIdx.y * npix;
     uint32_t n = 0;
-    for_my_events(pl, W, npix, [&](uint32_t, const PixelClass &) { n++; });
+    for_my_events(pl, W, npix, [&](uint32_t, uint32_t, const PixelClass &) { n++; });
     uint32_t total;
     (void)block_excl_scan(n, wsum, &total);
     if (threadIdx.x == 0) tile_cnt[blockIdx.y * gridDim.x + blockIdx.x] = total;
@@ -156,24 +171,15 @@ __global__ __launch_bounds__(WTHREADS) void k_wide_emit(const T *__restrict__ pl
     // classify once: the thread's records wait in registers for their place (raster order: thread by thread)
     uint64_t mine[16];
     uint32_t n = 0;
-    {
-        const uint32_t first = blockIdx.x * WT + threadIdx.x * 16u;
-        Coord xy;
-        xy.set(first < npix ? first : 0u, W);
 #pragma unroll
-        for (uint32_t j = 0; j < 16u; j++) {
-            const uint32_t i = first + j;
-            mine[j] = ~0ull;
-            if (i < npix && i >= 2) {
-                const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
-                if (pc.cls != CLS_IN) {
-                    mine[j] = make_rec(pc.ctx, pc.val, i);
-                    n++;
-                }
-            }
-            xy.advance(1, W);
-        }
-    }
+    for (uint32_t j = 0; j < 16u; j++) mine[j] = ~0ull;
+    for_my_events(pl, W, npix, [&](uint32_t j, uint32_t i, const PixelClass &pc) {
+        // (j is a compile-time constant on the fast path; the general path is rare enough for a select chain)
+#pragma unroll
+        for (uint32_t q = 0; q < 16u; q++)
+            if (q == j) mine[q] = make_rec(pc.ctx, pc.val, i);
+        n++;
+    });
     uint32_t total;
     uint32_t at = tile_base[blockIdx.y * gridDim.x + blockIdx.x] + block_excl_scan(n, wsum, &total);
 #pragma unroll

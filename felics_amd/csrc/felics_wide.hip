@@ -354,8 +354,8 @@ constexpr uint32_t WIDE_HALVE = 1024;   // COUNT_SCALING (traits.rs:40)
 // Rice parameter the lanes' code lengths are prefix-summed, which gives each lane the counters as
 // they were before its event (-> its k: smallest counter, ties to the largest k, parameter_selection.rs
 // :71-85) and after it.  The counters are halved after the first event that lifts their minimum above
-// 1024 (:58-68); that minimum never decreases along the block, so the event is found with one ballot,
-// the counters are halved there and the rest of the block is scanned again from the halved state.
+// 1024 (:58-68); that minimum never decreases along the block, so the event is found with one ballot and
+// the counters are halved there in place (the prefix sums stay valid for the lanes behind it).
 // The next block's records are in flight while this one is resolved.
 __global__ __launch_bounds__(256) void k_wide_chains(const uint64_t *__restrict__ recs, const uint32_t *__restrict__ meta,
                                                      uint32_t nplanes, uint32_t npix, const uint64_t *__restrict__ heads,
@@ -384,33 +384,49 @@ __global__ __launch_bounds__(256) void k_wide_chains(const uint64_t *__restrict_
             if (nvalid == 64u) cur = j + 64u + lane < plane_end ? recs[j + 64u + lane] : ~0ull;  // next block, in flight
             const uint32_t pix = rec_pix(mine);
             const uint32_t e = valid ? rec_e(mine) : 0u;
+            // One set of prefix sums per block; a halving at lane f turns the counters into ((S + P(f)) >> 1) - P(f), to which the
+            // lanes behind f add their own P(t) >= P(f) again (mod 2^32) -- no second scan.
+            uint32_t P[WIDE_NK], len[WIDE_NK];
+#pragma unroll
+            for (int k = 0; k < WIDE_NK; k++) {
+                len[k] = valid ? (e >> k) + 1u + (uint32_t)k : 0u;  // rice_coding.rs:40-46
+                P[k] = wave_incl_scan(len[k]);
+            }
             uint32_t base = 0;  // first event of the block not yet resolved
-            while (base < nvalid) {
-                const bool live = valid && lane >= base;
+            uint32_t my_k = 0;
+            while (true) {
                 uint32_t best_k = 0, best = 0xFFFFFFFFu, after_min = 0xFFFFFFFFu;
-                uint32_t P[WIDE_NK];
 #pragma unroll
                 for (int k = 0; k < WIDE_NK; k++) {
-                    const uint32_t len = live ? (e >> k) + 1u + (uint32_t)k : 0u;  // rice_coding.rs:40-46
-                    const uint32_t inc = wave_incl_scan(len);
-                    P[k] = inc;
-                    const uint32_t before = S[k] + inc - len;
+                    const uint32_t after = S[k] + P[k], before = after - len[k];
                     if (before <= best) {
                         best = before;
                         best_k = (uint32_t)k;
                     }
-                    after_min = min(after_min, S[k] + inc);
+                    after_min = min(after_min, after);
                 }
+                const bool live = valid && lane >= base;
                 const uint64_t hm = __ballot(live && after_min > WIDE_HALVE);
-                const uint32_t f = hm ? (uint32_t)__builtin_ctzll(hm) : nvalid - 1u;  // last event served by this scan
-                if (live && lane <= f) kp[pix] = (uint8_t)best_k;
+                const uint32_t f = hm ? (uint32_t)__builtin_ctzll(hm) : nvalid - 1u;  // last event served by these counters
+                if (live && lane <= f) my_k = best_k;
+                if (!hm) {
+#pragma unroll
+                    for (int k = 0; k < WIDE_NK; k++) S[k] += readlane(P[k], nvalid - 1u);
+                    break;
+                }
 #pragma unroll
                 for (int k = 0; k < WIDE_NK; k++) {
-                    const uint32_t s = S[k] + readlane(P[k], f);
-                    S[k] = hm ? s >> 1 : s;
+                    const uint32_t pf = readlane(P[k], f);
+                    S[k] = ((S[k] + pf) >> 1) - pf;
                 }
                 base = f + 1u;
+                if (base >= nvalid) {  // the halving fell on the block's last event: carry the counters over as they are
+#pragma unroll
+                    for (int k = 0; k < WIDE_NK; k++) S[k] += readlane(P[k], nvalid - 1u);
+                    break;
+                }
             }
+            if (valid) kp[pix] = (uint8_t)my_k;
             if (nvalid < 64u) break;
             j += 64u;
         }

@@ -928,6 +928,10 @@ int felics_ctx_create(int device, felics_ctx **out) {
     // the kernels that trail behind (k, lengths, pack) do not delay them when the GPU is full.
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);  // numerically: low >= high
+    if (const char *e = getenv("FELICS_PRIO")) {  // experiments: "flat" = one priority for all streams, "inverse" = tail first
+        if (strcmp(e, "flat") == 0) prio_low = prio_high = 0;
+        if (strcmp(e, "inverse") == 0) std::swap(prio_low, prio_high);
+    }
     for (Lane &l : ctx->lanes) {
         ok = ok && hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio_high) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&l.front, hipStreamNonBlocking, prio_high) == hipSuccess;

@@ -622,11 +622,15 @@ __device__ __forceinline__ void assign_block(const BlockIn &in, const uint32_t v
 
 // The same for the pack stage's own use (k_pack_k): k goes to an LDS array indexed by pixel (pix - pix0), only for
 // the lanes whose events belong to the caller's tile (`mine`); lanes at or behind `nlive` hold no event yet.
-__device__ __forceinline__ void assign_block_lds(const BlockIn &in, const bool mine, const uint32_t nlive, uint8_t *kq, uint32_t pix0) {
+// The block's start state arrives as one register (lane l holds S[l & 7], as the spine stored it), so that a ring of
+// prefetched blocks costs three registers per entry; it lives in scalar registers from here on.
+__device__ __forceinline__ void assign_block_lds(const uint32_t e, const uint32_t pix, const uint32_t st, const bool mine,
+                                                 const uint32_t nlive, uint8_t *kq, uint32_t pix0) {
     const uint32_t lane = lane_id();
-    uint32_t S0 = in.sa.x, S1 = in.sa.y, S2 = in.sa.z, S3 = in.sa.w, S4 = in.sb.x, S5 = in.sb.y;
+    uint32_t S0 = readlane(st, 0), S1 = readlane(st, 1), S2 = readlane(st, 2), S3 = readlane(st, 3), S4 = readlane(st, 4),
+             S5 = readlane(st, 5);
     uint32_t l01, l23, l45;
-    packed_lengths(in.e, l01, l23, l45);
+    packed_lengths(e, l01, l23, l45);
     const uint32_t p01 = wave_incl_scan(l01), p23 = wave_incl_scan(l23), p45 = wave_incl_scan(l45);
     const uint32_t P0 = p01 & 0xFFFFu, P1 = p01 >> 16, P2 = p23 & 0xFFFFu, P3 = p23 >> 16;
     const uint32_t P4 = p45 & 0xFFFFu, P5 = p45 >> 16;
@@ -636,6 +640,7 @@ __device__ __forceinline__ void assign_block_lds(const BlockIn &in, const bool m
     while (true) {
         const uint32_t T0 = S0 + P0, T1 = S1 + P1, T2 = S2 + P2, T3 = S3 + P3, T4 = S4 + P4, T5 = S5 + P5;
         const uint32_t mn = min(min(min(T0, T1), min(T2, T3)), min(T4, T5));
+        // state BEFORE this lane's event -> its k (get_k precedes update, compression.rs:127,139)
         const uint32_t X0 = T0 - l0, X1 = T1 - l1, X2 = T2 - l2, X3 = T3 - l3, X4 = T4 - l4, X5 = T5 - l5;
         const uint32_t key = min(min(min((X0 << 3) | 7u, (X1 << 3) | 6u), min((X2 << 3) | 5u, (X3 << 3) | 4u)),
                                  min((X4 << 3) | 3u, (X5 << 3) | 2u));
@@ -654,7 +659,7 @@ __device__ __forceinline__ void assign_block_lds(const BlockIn &in, const bool m
         lo = f + 1;
         if (lo >= nlive) break;
     }
-    if (mine) kq[in.pix - pix0] = (uint8_t)kk;
+    if (mine) kq[pix - pix0] = (uint8_t)kk;
 }
 
 // Tags are dealt to the waves one by one (tag g belongs to wave g % nwaves): the blocks a spine launch
@@ -731,6 +736,7 @@ struct TileLDS {
     alignas(16) T cur[STAGE_LEAD + PACK_TILE];  // cur[STAGE_LEAD + j] = pixel tile_first + j
     alignas(16) T up[PACK_TILE + 16];            // up[j] = pixel tile_first - W + j
     alignas(16) uint8_t kq[PACK_TILE];           // k of pixel tile_first + j
+    alignas(16) uint32_t dump[4];                // where stage_pixels puts the chunks it does not want
 };
 
 // lds[j] = g[first + j] for j in [0, count), indices outside [0, limit) skipped; 16-byte copies
@@ -755,10 +761,60 @@ __device__ __forceinline__ void stage_span(U *lds, const U *__restrict__ g, int6
     }
 }
 
+// cur and up of one tile.  All 16-byte loads of both spans are issued before the first of them is waited for (one
+// memory round trip instead of one per span and trip); chunks at the ends of the plane, or of a span that is not
+// 16-byte aligned in memory, go element by element afterwards.
 template <typename T>
 __device__ __forceinline__ void stage_pixels(TileLDS<T> &t, const T *__restrict__ pl, uint32_t tile_first, uint32_t W, uint32_t npix) {
-    stage_span<T>(t.cur, pl, (int64_t)tile_first - STAGE_LEAD, STAGE_LEAD + PACK_TILE, npix);
-    stage_span<T>(t.up, pl, (int64_t)tile_first - W, PACK_TILE + 16, npix);
+    constexpr uint32_t EPC = 16 / sizeof(T);  // elements per 16-byte chunk
+    constexpr uint32_t NA = (STAGE_LEAD + PACK_TILE) / EPC, NB = (PACK_TILE + 16) / EPC;
+    constexpr uint32_t KA = (NA + PACK_THREADS - 1) / PACK_THREADS, KB = (NB + PACK_THREADS - 1) / PACK_THREADS;
+    static_assert((STAGE_LEAD + PACK_TILE) % EPC == 0 && (PACK_TILE + 16) % EPC == 0, "whole chunks");
+    const int64_t fa = (int64_t)tile_first - STAGE_LEAD, fb = (int64_t)tile_first - W;
+    const bool ala = ((reinterpret_cast<uintptr_t>(pl) + (uint64_t)fa * sizeof(T)) & 15u) == 0;
+    const bool alb = ((reinterpret_cast<uintptr_t>(pl) + (uint64_t)fb * sizeof(T)) & 15u) == 0;
+    uint4 va[KA], vb[KB];
+    bool wa[KA], wb[KB];
+    // what a chunk that is not loaded this way reads instead: the 16 aligned bytes the plane starts in (the planes of a
+    // batch lie in one allocation, so these exist)
+    const uint4 *safe = reinterpret_cast<const uint4 *>(pl - (reinterpret_cast<uintptr_t>(pl) & 15u) / sizeof(T));
+#pragma unroll
+    for (uint32_t k = 0; k < KA; k++) {
+        const uint32_t c = threadIdx.x + k * PACK_THREADS;
+        const int64_t g0 = fa + (int64_t)c * EPC;
+        wa[k] = c < NA && ala && g0 >= 0 && g0 + EPC <= (int64_t)npix;
+        va[k] = *(wa[k] ? reinterpret_cast<const uint4 *>(pl + g0) : safe);  // (no branch: a branch would be a wait per load)
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < KB; k++) {
+        const uint32_t c = threadIdx.x + k * PACK_THREADS;
+        const int64_t g0 = fb + (int64_t)c * EPC;
+        wb[k] = c < NB && alb && g0 >= 0 && g0 + EPC <= (int64_t)npix;
+        vb[k] = *(wb[k] ? reinterpret_cast<const uint4 *>(pl + g0) : safe);
+    }
+    auto slowly = [&](T *lds, int64_t first, uint32_t c) {
+        for (uint32_t e = 0; e < EPC; e++) {
+            const int64_t gi = first + (int64_t)c * EPC + e;
+            if (gi >= 0 && gi < (int64_t)npix) lds[c * EPC + e] = pl[gi];
+        }
+    };
+    // (every load is stored, the unwanted ones into a dump slot: a load that is only used under a condition is moved
+    // under that condition by the compiler, and then waited for there, one by one)
+    uint4 *dump = reinterpret_cast<uint4 *>(t.dump);
+#pragma unroll
+    for (uint32_t k = 0; k < KA; k++) *(wa[k] ? reinterpret_cast<uint4 *>(t.cur) + (threadIdx.x + k * PACK_THREADS) : dump) = va[k];
+#pragma unroll
+    for (uint32_t k = 0; k < KB; k++) *(wb[k] ? reinterpret_cast<uint4 *>(t.up) + (threadIdx.x + k * PACK_THREADS) : dump) = vb[k];
+#pragma unroll
+    for (uint32_t k = 0; k < KA; k++) {
+        const uint32_t c = threadIdx.x + k * PACK_THREADS;
+        if (!wa[k] && c < NA) slowly(t.cur, fa, c);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < KB; k++) {
+        const uint32_t c = threadIdx.x + k * PACK_THREADS;
+        if (!wb[k] && c < NB) slowly(t.up, fb, c);
+    }
 }
 
 template <typename T>
@@ -1099,7 +1155,7 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ pla
 // ------------------------------------------------------------------------------------------
 
 constexpr uint32_t LOCAL_WORDS = 8;
-constexpr uint32_t FUSED_WIN_WORDS = 1280;  // LDS bit window: 10 bits per pixel of a tile in one pass (more bits: more passes)
+constexpr uint32_t FUSED_WIN_WORDS = PACK_TILE * 10 / 32;  // LDS bit window: 10 bits per pixel of a tile in one pass (more bits: more passes)
 // thread-private bit string, MSB-first, word w of thread t at buf[w * PACK_THREADS + t]
 struct LocalBits {
     uint32_t *buf;
@@ -1159,7 +1215,23 @@ struct FusedArgs {
     uint32_t *ticket;
     uint32_t nplanes;
 };
+#ifdef FELICS_PACK_STAMPS
+__device__ unsigned long long g_pack_stamps[256][16];
+#define PSTAMP(i)                                                                              \
+    do {                                                                                       \
+        if (threadIdx.x == 0) {                                                                \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                      \
+            fl.t_acc[i] = now_ - fl.t_last;                                                    \
+            fl.t_last = now_;                                                                  \
+        }                                                                                      \
+    } while (0)
+#else
+#define PSTAMP(i)
+#endif
 struct FusedLDS {
+#ifdef FELICS_PACK_STAMPS
+    unsigned long long t_last, t_acc[12];
+#endif
     uint32_t win[FUSED_WIN_WORDS];
     uint32_t lbuf[LOCAL_WORDS * PACK_THREADS];
     uint32_t wsum[PACK_THREADS / 64];
@@ -1196,11 +1268,11 @@ __device__ __forceinline__ void pack_tile_fused(TileLDS<T> &tl, const uint8_t *k
     const bool has_header = tile == 0 && threadIdx.x == 0 && first_plane;
     uint64_t *my_status = status + (uint64_t)plane * ntiles + tile;
 
-    if (k_map)
+    if (k_map) {  // (null: the caller has put the pixels and k into LDS, with a barrier behind them)
         stage_tile(tl, pl, k_map + (uint64_t)plane * npix, tile_first, W, npix);
-    else
-        stage_pixels(tl, pl, tile_first, W, npix);  // (k is in LDS already)
-    __syncthreads();
+        __syncthreads();
+    }
+    PSTAMP(4);
 
     // ---- phase 1: this thread's bit string
     LocalBits lb;
@@ -1223,7 +1295,9 @@ __device__ __forceinline__ void pack_tile_fused(TileLDS<T> &tl, const uint8_t *k
     const uint32_t bits = lb.total;
     const uint32_t inc = wave_incl_scan(bits);
     if (lane == 63) wsum[wave] = inc;
+    PSTAMP(5);
     __syncthreads();
+    PSTAMP(6);
     uint32_t woff = 0, tile_total = 0;
     for (uint32_t w = 0; w < PACK_THREADS / 64; w++) {
         if (w < wave) woff += wsum[w];
@@ -1289,6 +1363,7 @@ __device__ __forceinline__ void pack_tile_fused(TileLDS<T> &tl, const uint8_t *k
         }
     }
     __syncthreads();
+    PSTAMP(7);
     const uint64_t tile_lo = tile_lo_sh, tile_hi = tile_lo + tile_total;
     const uint64_t my_lo = tile_lo + woff + inc - bits;
     uint64_t limit_words;  // a stream that outgrows its slot is cut (the host re-packs)
@@ -1352,7 +1427,26 @@ __device__ __forceinline__ void pack_tile_fused(TileLDS<T> &tl, const uint8_t *k
             }
         }
     }
+    PSTAMP(8);
+#ifdef FELICS_PACK_STAMPS
+    if (threadIdx.x == 0) {
+        unsigned long long *slot = g_pack_stamps[(tile * 7u + plane) & 255u];
+        for (int i = 0; i < 12; i++) atomicAdd(&slot[i], fl.t_acc[i]);
+        atomicAdd(&slot[15], 1ull);
+    }
+#endif
 }
+
+#ifdef FELICS_PACK_STAMPS
+extern "C" __attribute__((visibility("default"))) int felics_debug_pack_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pack_stamps), sizeof(g_pack_stamps)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long z[256 * 16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_pack_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // (u8 planes: six waves per SIMD -- 80 VGPRs, 25.6 KB of LDS per workgroup; i16 planes: four, 33.8 KB)
 template <typename T>
@@ -1387,45 +1481,118 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch
     static_assert(SORT_TILE == PACK_TILE, "one workgroup = one sort tile = one pack tile (one look-back per workgroup)");
     uint8_t *kq2 = tl.kq;
     uint32_t x, plane;
+#ifdef FELICS_PACK_STAMPS
+    if (threadIdx.x == 0) {
+        fl.t_last = __builtin_amdgcn_s_memtime();
+    }
+#endif
     take_ticket(fa, fl, x, plane);
+    PSTAMP(0);
     const uint32_t st = sort_tile_begin + x;
     const uint32_t lane = lane_id();
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     constexpr uint32_t NWV = PACK_THREADS / 64;
-    // ---- k of this sort tile's events.  Wave w takes the contexts w, w + 4, ...
+    // ---- k of this sort tile's events.  The 64-event blocks that overlap the tile's runs are listed in LDS first
+    // (thread t lists the blocks of contexts t and t + 256; the list lives in the bit window and the private bit
+    // buffers, which the pack stage only uses afterwards) and then dealt to the waves one by one: a synthetic or
+    // smooth frame has ten contexts that matter, so dealing whole contexts leaves one wave with a third more blocks
+    // than the average.  (Listing the runs instead and letting every wave walk that list with scalar code was measured:
+    // what the listing saves, the walk costs.)
     {
         const uint32_t *off0 = ks.tile_off + ((uint64_t)plane * ks.sort_ntiles + st) * NCTX;
         const bool last_tile = st + 1 == ks.sort_ntiles;
         const uint32_t *off1 = last_tile ? ks.chain_len + (uint64_t)plane * NCTX : off0 + NCTX;
         const uint32_t *cb = ks.chain_base + (uint64_t)plane * NCTX;
         const ET *sorted_e = reinterpret_cast<const ET *>(ks.sorted_e);
-        const uint4 *stt = reinterpret_cast<const uint4 *>(ks.block_state);
         const uint32_t pix0 = plane * fa.npix + st * SORT_TILE;  // pix_of holds plane * npix + i
-        for (uint32_t c0 = 0; c0 < NCTX; c0 += 64 * NWV) {
-            const uint32_t c = c0 + lane * NWV + wave;
-            const uint32_t a = off0[c], b = off1[c];
-            const uint32_t base = cb[c];
-            uint64_t todo = __ballot(b > a);
-            while (todo) {
-                const uint32_t l = (uint32_t)__builtin_ctzll(todo);
-                todo &= todo - 1;
-                const uint32_t sa = readlane(a, l) + readlane(base, l), sb = readlane(b, l) + readlane(base, l);  // slots [sa, sb)
-                for (uint32_t gb = sa >> 6; gb <= (sb - 1) >> 6; gb++) {
-                    BlockIn in = load_block<ET>(stt, sorted_e, ks.pix_of, gb);
-                    const uint32_t slot = gb * 64u + lane;
-                    if (slot >= sb) in.e = 0;  // not scattered yet (a later tile's events): whatever lies there is not an event
-                    assign_block_lds(in, slot >= sa && slot < sb, min(64u, sb - gb * 64u), kq2, pix0);
+        constexpr uint32_t CPT = NCTX / PACK_THREADS;  // contexts per thread
+        static_assert(NCTX == CPT * PACK_THREADS, "thread t lists contexts t, t + PACK_THREADS, ...");
+        constexpr uint32_t MAX_ITEMS = SORT_TILE / 64 + 2 * NCTX;  // a run of L events touches at most L / 64 + 2 blocks
+        static_assert(2 * MAX_ITEMS <= FUSED_WIN_WORDS + LOCAL_WORDS * PACK_THREADS && offsetof(FusedLDS, lbuf) == offsetof(FusedLDS, win) + sizeof(fl.win),
+                      "the block list borrows win + lbuf");
+        uint2 *items = reinterpret_cast<uint2 *>(fl.win);  // {block, first lane of the run | lanes with an event in place << 8}
+        uint32_t ra[CPT], rb[CPT], rbase[CPT];
+#pragma unroll
+        for (uint32_t h = 0; h < CPT; h++) {
+            const uint32_t c = threadIdx.x + h * PACK_THREADS;
+            ra[h] = off0[c];
+            rb[h] = off1[c];
+            rbase[h] = cb[c];
+        }
+        // the tile's pixels come in on the same round trip as the run table (the pack stage reads them from LDS)
+        stage_pixels(tl, planes + (uint64_t)plane * fa.npix, st * PACK_TILE, fa.W, fa.npix);
+        uint32_t sa[CPT], sb[CPT], nb[CPT];
+        uint32_t mine_n = 0;
+#pragma unroll
+        for (uint32_t h = 0; h < CPT; h++) {
+            const uint32_t a = ra[h], b = rb[h], base = rbase[h];
+            sa[h] = a + base;
+            sb[h] = b + base;  // slots [sa, sb)
+            nb[h] = b > a ? ((sb[h] - 1) >> 6) - (sa[h] >> 6) + 1 : 0u;
+            mine_n += nb[h];
+        }
+        PSTAMP(9);
+        const uint32_t incl = wave_incl_scan(mine_n);
+        if (lane == 63) fl.wsum[wave] = incl;
+        __syncthreads();
+        PSTAMP(10);
+        uint32_t at = incl - mine_n, nitems = 0;
+        for (uint32_t w = 0; w < NWV; w++) {
+            if (w < wave) at += fl.wsum[w];
+            nitems += fl.wsum[w];
+        }
+#pragma unroll
+        for (uint32_t h = 0; h < CPT; h++) {
+            for (uint32_t j = 0; j < nb[h]; j++) {
+                const uint32_t gb = (sa[h] >> 6) + j;
+                const uint32_t lo = sa[h] > gb * 64u ? sa[h] - gb * 64u : 0u, hi = min(64u, sb[h] - gb * 64u);
+                items[at++] = make_uint2(gb, lo | (hi << 8));
+            }
+        }
+        __syncthreads();
+        PSTAMP(1);
+        nitems = (uint32_t)__builtin_amdgcn_readfirstlane((int)nitems);
+        // A wave's blocks go through a ring of RING prefetched entries (event, pixel and start state: three registers
+        // each): with one block in flight per wave the stage was one memory round trip per block, ~19 in a row per tile.
+        // Every refill is issued whether or not the entry is used (the index is clamped), so the number of loads in
+        // flight is the same on every path.
+        constexpr uint32_t RING = 6;
+        uint32_t re[RING], rp[RING], rs[RING], rr[RING];
+        const uint32_t *stw = ks.block_state;
+        auto fetch = [&](uint32_t &e, uint32_t &px, uint32_t &sv, uint32_t &rng, uint32_t idx) {
+            const uint2 it = items[min(idx, nitems - 1u)];
+            rng = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.y);
+            const uint32_t gb = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.x);
+            e = (uint32_t)sorted_e[(uint64_t)gb * 64 + lane];
+            px = ks.pix_of[(uint64_t)gb * 64 + lane];
+            sv = stw[(uint64_t)gb * 8 + (lane & 7u)];
+        };
+        if (nitems != 0) {
+#pragma unroll
+            for (uint32_t d = 0; d < RING; d++) {
+                fetch(re[d], rp[d], rs[d], rr[d], wave + d * NWV);
+                __builtin_amdgcn_sched_barrier(0);  // (entry 0 first: the loop consumes the entries in this order)
+            }
+            for (uint32_t i = wave; i < nitems; i += NWV * RING) {
+#pragma unroll
+                for (uint32_t d = 0; d < RING; d++) {
+                    const uint32_t idx = i + d * NWV;
+                    uint32_t e = re[d];
+                    const uint32_t px = rp[d], sv = rs[d], rng = rr[d];
+                    fetch(re[d], rp[d], rs[d], rr[d], idx + NWV * RING);
+                    if (idx < nitems) {
+                        const uint32_t lo = rng & 0xFFu, hi = rng >> 8;
+                        if (lane >= hi) e = 0;  // not scattered yet (a later tile's events): whatever lies there is not an event
+                        assign_block_lds(e, px, sv, lane >= lo && lane < hi, hi, kq2, pix0);
+                    }
                 }
             }
         }
     }
+    PSTAMP(2);
     __syncthreads();
-    for (uint32_t half = 0; half < SORT_TILE / PACK_TILE; half++) {
-        const uint32_t tile = st * (SORT_TILE / PACK_TILE) + half;
-        if (tile >= pack_tile_end) break;
-        pack_tile_fused<T>(tl, kq2 + half * PACK_TILE, fl, planes, nullptr, fa, tile, plane);
-        __syncthreads();
-    }
+    PSTAMP(3);
+    if (st < pack_tile_end) pack_tile_fused<T>(tl, kq2, fl, planes, nullptr, fa, st, plane);
 }
 
 // Words shared by two tiles (and the last, partly filled word of a plane): OR of the two halves.

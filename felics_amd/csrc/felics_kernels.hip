@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
                                                  ET *__restrict__ sorted_e, uint32_t *__restrict__ pix_of,
                                                  uint32_t W, uint32_t npix, uint32_t ntiles, uint32_t tile_begin,
                                                  uint32_t tile_end) {
-    constexpr uint32_t RING = 6;  // a trip adds at most 256 events to fewer than 64 left over
+    constexpr uint32_t RING = 512;  // a trip adds at most 256 events to fewer than 64 left over
     static_assert(SORT_TILE <= (1u << 13), "ring records keep the pixel's offset in its tile in 13 bits");
     __shared__ uint32_t runs[4][NCTX];
     __shared__ uint32_t rings[4][RING];
@@ -1552,13 +1552,12 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch
         __syncthreads();
         PSTAMP(1);
         nitems = (uint32_t)__builtin_amdgcn_readfirstlane((int)nitems);
-        // A wave's blocks go through a ring of RING prefetched entries (event, pixel and start state: three registers
+        // A wave's blocks go through a ring of AHEAD prefetched entries (event, pixel and start state: three registers
         // each): with one block in flight per wave the stage was one memory round trip per block, ~19 in a row per tile.
         // Every refill is issued whether or not the entry is used (the index is clamped), so the number of loads in
-        // flight is the same on every path.  (Six entries: builds with 8 and 12 produced wrong streams on the GPU -- the
-        // cause was not found in the generated code, so the depth stays where the whole suite passes.)
-        constexpr uint32_t RING = 6;
-        uint32_t re[RING], rp[RING], rs[RING], rr[RING];
+        // flight is the same on every path.
+        constexpr uint32_t AHEAD = 6;
+        uint32_t re[AHEAD], rp[AHEAD], rs[AHEAD], rr[AHEAD];
         const uint32_t *stw = ks.block_state;
         auto fetch = [&](uint32_t &e, uint32_t &px, uint32_t &sv, uint32_t &rng, uint32_t idx) {
             const uint2 it = items[min(idx, nitems - 1u)];
@@ -1570,17 +1569,17 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch
         };
         if (nitems != 0) {
 #pragma unroll
-            for (uint32_t d = 0; d < RING; d++) {
+            for (uint32_t d = 0; d < AHEAD; d++) {
                 fetch(re[d], rp[d], rs[d], rr[d], wave + d * NWV);
                 __builtin_amdgcn_sched_barrier(0);  // (entry 0 first: the loop consumes the entries in this order)
             }
-            for (uint32_t i = wave; i < nitems; i += NWV * RING) {
+            for (uint32_t i = wave; i < nitems; i += NWV * AHEAD) {
 #pragma unroll
-                for (uint32_t d = 0; d < RING; d++) {
+                for (uint32_t d = 0; d < AHEAD; d++) {
                     const uint32_t idx = i + d * NWV;
                     uint32_t e = re[d];
                     const uint32_t px = rp[d], sv = rs[d], rng = rr[d];
-                    fetch(re[d], rp[d], rs[d], rr[d], idx + NWV * RING);
+                    fetch(re[d], rp[d], rs[d], rr[d], idx + NWV * AHEAD);
                     if (idx < nitems) {
                         const uint32_t lo = rng & 0xFFu, hi = rng >> 8;
                         if (lane >= hi) e = 0;  // not scattered yet (a later tile's events): whatever lies there is not an event

@@ -339,7 +339,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     {
         StageTimer t(ctx, l, ST_OFFSETS, f);
         launch_offsets(f, counts, chain_len, chain_base, (uint32_t *)l.scalars.p, g);
-        launch_zero_padding<ET>(f, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, chain_base, chain_len, g);
+        launch_zero_padding<ET>(f, (ET *)l.sorted_e.p, ink ? nullptr : (uint32_t *)l.pix_of.p, chain_base, chain_len, g);
         HIP_TRY(ctx, hipMemsetAsync(chain_prog, 0, (size_t)g.nplanes * NCTX * 32, f));
         HIP_TRY(ctx, hipMemsetAsync(l.partial.p, 0, (size_t)ns * g.nplanes * NCTX * 8, f));
     }
@@ -351,7 +351,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     for (int q = 0; q < ns; q++) {
         if (bounds[q + 1] != bounds[q]) {
             StageTimer t(ctx, l, ST_SCATTER, f, true);
-            launch_scatter<T, ET>(f, d_planes, counts, chain_base, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, g,
+            launch_scatter<T, ET>(f, d_planes, counts, chain_base, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, ink, g,
                                   bounds[q], bounds[q + 1]);
         }
         HIP_TRY(ctx, hipEventRecord(l.slice_done[q], f));

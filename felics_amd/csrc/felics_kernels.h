@@ -71,7 +71,10 @@ void launch_offsets(hipStream_t s, uint32_t *counts, uint32_t *chain_len, uint32
 // scatter works on a slice [tile_begin, tile_end) of every plane's tiles
 template <typename T, typename ET>
 void launch_scatter(hipStream_t s, const T *planes, const uint32_t *tile_off, const uint32_t *chain_base,
-                    ET *sorted_e, uint32_t *pix_of, const Geometry &g, uint32_t tile_begin, uint32_t tile_end);
+                    ET *sorted_e, uint32_t *pix_of, bool in_tile_offsets, const Geometry &g, uint32_t tile_begin, uint32_t tile_end);
+// pix_of holds, per event slot, where the event's pixel is: plane * npix + i as 32 bits (k_assign writes k by pixel), or
+// -- in_tile_offsets, for launch_pack_k, whose workgroups know their tile -- i - tile * SORT_TILE as 16 bits in the same
+// buffer (launch_zero_padding then gets a null pix_of: the padding slots are never read).
 
 // Chains are padded to whole 64-event blocks: upper bounds of the slot / block counts of a pass.
 inline uint64_t max_event_slots(const Geometry &g) {

@@ -250,17 +250,18 @@ __global__ void k_zero_padding(ET *__restrict__ sorted_e, uint32_t *__restrict__
     const uint32_t n = chain_len[c], base = chain_base[c];
     for (uint32_t i = n; i < ((n + 63u) & ~63u); i++) {
         sorted_e[base + i] = 0;
-        pix_of[base + i] = 0xFFFFFFFFu;
+        if (pix_of) pix_of[base + i] = 0xFFFFFFFFu;  // (null: in-tile offsets, read by run and never in the padding)
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // scatter: stable partition of events by context.  One wave per tile walks its pixels in
 // raster order, 64 at a time; lanes that hold the same context rank themselves with a ballot.
-// sorted_e[slot] = value to Rice-code; pix_of[slot] = plane*npix + i, the pixel the event came from.
+// sorted_e[slot] = value to Rice-code; pix_of[slot] = the pixel the event came from: plane*npix + i (32 bits) for
+// k_assign, or -- REL, what k_pack_k reads -- the pixel's offset in its sort tile (16 bits, the same buffer).
 // ------------------------------------------------------------------------------------------
 
-template <typename T, typename ET>
+template <typename T, typename ET, bool REL>
 __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
                                                  const uint32_t *__restrict__ tile_off,
                                                  const uint32_t *__restrict__ chain_base,
@@ -326,7 +327,10 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
         __builtin_amdgcn_wave_barrier();
         if (ev) {
             sorted_e[dest] = (ET)e;
-            pix_of[dest] = plane_first + begin + off;
+            if (REL)  // the pack stage that computes k itself knows its tile: two bytes per event instead of four
+                reinterpret_cast<uint16_t *>(pix_of)[dest] = (uint16_t)off;
+            else
+                pix_of[dest] = plane_first + begin + off;
         }
     };
     uint32_t y0 = begin / W, x0 = begin - y0 * W;
@@ -620,12 +624,12 @@ __device__ __forceinline__ void assign_block(const BlockIn &in, const uint32_t v
     if (lane < valid && in.pix != 0xFFFFFFFFu) k_map[in.pix] = (uint8_t)kk;
 }
 
-// The same for the pack stage's own use (k_pack_k): k goes to an LDS array indexed by pixel (pix - pix0), only for
+// The same for the pack stage's own use (k_pack_k): k goes to an LDS array indexed by the pixel's offset in the tile, only for
 // the lanes whose events belong to the caller's tile (`mine`); lanes at or behind `nlive` hold no event yet.
 // The block's start state arrives as one register (lane l holds S[l & 7], as the spine stored it), so that a ring of
 // prefetched blocks costs three registers per entry; it lives in scalar registers from here on.
 __device__ __forceinline__ void assign_block_lds(const uint32_t e, const uint32_t pix, const uint32_t st, const bool mine,
-                                                 const uint32_t nlive, uint8_t *kq, uint32_t pix0) {
+                                                 const uint32_t nlive, uint8_t *kq) {
     const uint32_t lane = lane_id();
     uint32_t S0 = readlane(st, 0), S1 = readlane(st, 1), S2 = readlane(st, 2), S3 = readlane(st, 3), S4 = readlane(st, 4),
              S5 = readlane(st, 5);
@@ -659,7 +663,7 @@ __device__ __forceinline__ void assign_block_lds(const uint32_t e, const uint32_
         lo = f + 1;
         if (lo >= nlive) break;
     }
-    if (mine) kq[pix - pix0] = (uint8_t)kk;
+    if (mine) kq[pix] = (uint8_t)kk;
 }
 
 // Tags are dealt to the waves one by one (tag g belongs to wave g % nwaves): the blocks a spine launch
@@ -1469,7 +1473,8 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch
 
 struct KSources {
     const void *sorted_e;
-    const uint32_t *pix_of, *block_state, *tile_off, *chain_base, *chain_len;
+    const uint16_t *pix_of;  // offset of the event's pixel in its sort tile
+    const uint32_t *block_state, *tile_off, *chain_base, *chain_len;
     uint32_t sort_ntiles;
 };
 
@@ -1478,6 +1483,11 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch
                                                                                                uint32_t sort_tile_begin, uint32_t pack_tile_end) {
     __shared__ TileLDS<T> tl;
     __shared__ FusedLDS fl;
+#ifdef FELICS_PACK_PAD_LDS  // experiment: fewer workgroups per CU, same code
+    __shared__ uint32_t pad_lds[FELICS_PACK_PAD_LDS / 4];
+    if (fa.epoch == 0xFFFFFFFFu) pad_lds[threadIdx.x] = fa.W;
+    if (fa.epoch == 0xFFFFFFFEu) fa.error[0] = pad_lds[threadIdx.x ^ 1];
+#endif
     static_assert(SORT_TILE == PACK_TILE, "one workgroup = one sort tile = one pack tile (one look-back per workgroup)");
     uint8_t *kq2 = tl.kq;
     uint32_t x, plane;
@@ -1504,7 +1514,6 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch
         const uint32_t *off1 = last_tile ? ks.chain_len + (uint64_t)plane * NCTX : off0 + NCTX;
         const uint32_t *cb = ks.chain_base + (uint64_t)plane * NCTX;
         const ET *sorted_e = reinterpret_cast<const ET *>(ks.sorted_e);
-        const uint32_t pix0 = plane * fa.npix + st * SORT_TILE;  // pix_of holds plane * npix + i
         constexpr uint32_t CPT = NCTX / PACK_THREADS;  // contexts per thread
         static_assert(NCTX == CPT * PACK_THREADS, "thread t lists contexts t, t + PACK_THREADS, ...");
         constexpr uint32_t MAX_ITEMS = SORT_TILE / 64 + 2 * NCTX;  // a run of L events touches at most L / 64 + 2 blocks
@@ -1564,7 +1573,7 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch
             rng = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.y);
             const uint32_t gb = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.x);
             e = (uint32_t)sorted_e[(uint64_t)gb * 64 + lane];
-            px = ks.pix_of[(uint64_t)gb * 64 + lane];
+            px = (uint32_t)ks.pix_of[(uint64_t)gb * 64 + lane];
             sv = stw[(uint64_t)gb * 8 + (lane & 7u)];
         };
         if (nitems != 0) {
@@ -1583,7 +1592,7 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch
                     if (idx < nitems) {
                         const uint32_t lo = rng & 0xFFu, hi = rng >> 8;
                         if (lane >= hi) e = 0;  // not scattered yet (a later tile's events): whatever lies there is not an event
-                        assign_block_lds(e, px, sv, lane >= lo && lane < hi, hi, kq2, pix0);
+                        assign_block_lds(e, px, sv, lane >= lo && lane < hi, hi, kq2);
                     }
                 }
             }
@@ -1684,15 +1693,19 @@ void launch_offsets(hipStream_t s, uint32_t *counts, uint32_t *chain_len, uint32
 
 template <typename T, typename ET>
 void launch_scatter(hipStream_t s, const T *planes, const uint32_t *tile_off, const uint32_t *chain_base,
-                    ET *sorted_e, uint32_t *pix_of, const Geometry &g, uint32_t tile_begin, uint32_t tile_end) {
+                    ET *sorted_e, uint32_t *pix_of, bool in_tile_offsets, const Geometry &g, uint32_t tile_begin, uint32_t tile_end) {
     if (tile_end <= tile_begin) return;
-    FELICS_LAUNCH((k_scatter<T, ET>), dim3(cdiv(tile_end - tile_begin, 4), g.nplanes), dim3(256), s, planes,
-                       tile_off, chain_base, sorted_e, pix_of, g.W, g.npix, g.sort_tiles, tile_begin, tile_end);
+    if (in_tile_offsets)
+        FELICS_LAUNCH((k_scatter<T, ET, true>), dim3(cdiv(tile_end - tile_begin, 4), g.nplanes), dim3(256), s, planes,
+                           tile_off, chain_base, sorted_e, pix_of, g.W, g.npix, g.sort_tiles, tile_begin, tile_end);
+    else
+        FELICS_LAUNCH((k_scatter<T, ET, false>), dim3(cdiv(tile_end - tile_begin, 4), g.nplanes), dim3(256), s, planes,
+                           tile_off, chain_base, sorted_e, pix_of, g.W, g.npix, g.sort_tiles, tile_begin, tile_end);
 }
 template void launch_scatter<uint8_t, uint8_t>(hipStream_t, const uint8_t *, const uint32_t *, const uint32_t *,
-                                               uint8_t *, uint32_t *, const Geometry &, uint32_t, uint32_t);
+                                               uint8_t *, uint32_t *, bool, const Geometry &, uint32_t, uint32_t);
 template void launch_scatter<int16_t, uint16_t>(hipStream_t, const int16_t *, const uint32_t *, const uint32_t *,
-                                                uint16_t *, uint32_t *, const Geometry &, uint32_t, uint32_t);
+                                                uint16_t *, uint32_t *, bool, const Geometry &, uint32_t, uint32_t);
 
 template <typename ET>
 void launch_zero_padding(hipStream_t s, ET *sorted_e, uint32_t *pix_of, const uint32_t *chain_base,
@@ -1840,7 +1853,7 @@ void launch_pack_k(hipStream_t s, const T *planes, const ET *sorted_e, const uin
     const FusedArgs fa{status, tile_bitoff, tile_bits, plane_carry, edge_first, edge_last, error,
                        PlaneOut{to.out, to.slot_stride, to.scratch, to.plane_slot, g.planes_per_image},
                        g.W, g.H, g.npix, g.pack_tiles, g.color, g.depth, epoch, ticket, g.nplanes};
-    const KSources ks{sorted_e, pix_of, block_state, tile_off, chain_base, chain_len, g.sort_tiles};
+    const KSources ks{sorted_e, reinterpret_cast<const uint16_t *>(pix_of), block_state, tile_off, chain_base, chain_len, g.sort_tiles};
     FELICS_LAUNCH((k_pack_k<T, ET>), dim3(st1 - st0, g.nplanes), dim3(PACK_THREADS), s, planes, ks, fa, st0, g.pack_tiles);
 }
 template void launch_pack_k<uint8_t, uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, const uint32_t *, const uint32_t *,

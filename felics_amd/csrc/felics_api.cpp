@@ -263,16 +263,16 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     const size_t nsamples = (size_t)g.nplanes * g.npix;
     const size_t slots = (size_t)max_event_slots(g);
     int rc;
-    if ((rc = reserve(ctx, l.counts, (size_t)g.nplanes * g.sort_tiles * NCTX * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, l.chain_len, (size_t)g.nplanes * NCTX * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, l.chain_base, (size_t)g.nplanes * NCTX * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, l.chain_prog, (size_t)g.nplanes * NCTX * 32)) != 0) return rc;
+    if ((rc = reserve(ctx, l.counts, (size_t)g.nplanes * g.sort_tiles * g.nctx * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.chain_len, (size_t)g.nplanes * g.nctx * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.chain_base, (size_t)g.nplanes * g.nctx * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.chain_prog, (size_t)g.nplanes * g.nctx * 32)) != 0) return rc;
     if ((rc = reserve(ctx, l.scalars, 64 + 4 * (SLICES + 2))) != 0) return rc;
     if ((rc = reserve(ctx, l.sorted_e, slots * sizeof(ET) + SORTED_PAD)) != 0) return rc;
     if ((rc = reserve(ctx, l.pix_of, slots * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.k_map, nsamples + STAGE_PAD)) != 0) return rc;
     if ((rc = reserve(ctx, l.block_state, (size_t)max_event_blocks(g) * 32)) != 0) return rc;
-    if ((rc = reserve(ctx, l.partial, (size_t)SLICES * g.nplanes * NCTX * 8)) != 0) return rc;
+    if ((rc = reserve(ctx, l.partial, (size_t)SLICES * g.nplanes * g.nctx * 8)) != 0) return rc;
     if ((rc = reserve_zeroed(ctx, l.block_tag, (size_t)max_event_blocks(g) * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.group_bits, (size_t)g.nplanes * g.pack_tiles * PACK_THREADS * 2)) != 0) return rc;
     if ((rc = reserve(ctx, l.tile_bits, (size_t)g.nplanes * g.pack_tiles * 4)) != 0) return rc;
@@ -340,8 +340,8 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         StageTimer t(ctx, l, ST_OFFSETS, f);
         launch_offsets(f, counts, chain_len, chain_base, (uint32_t *)l.scalars.p, g);
         launch_zero_padding<ET>(f, (ET *)l.sorted_e.p, ink ? nullptr : (uint32_t *)l.pix_of.p, chain_base, chain_len, g);
-        HIP_TRY(ctx, hipMemsetAsync(chain_prog, 0, (size_t)g.nplanes * NCTX * 32, f));
-        HIP_TRY(ctx, hipMemsetAsync(l.partial.p, 0, (size_t)ns * g.nplanes * NCTX * 8, f));
+        HIP_TRY(ctx, hipMemsetAsync(chain_prog, 0, (size_t)g.nplanes * g.nctx * 32, f));
+        HIP_TRY(ctx, hipMemsetAsync(l.partial.p, 0, (size_t)ns * g.nplanes * g.nctx * 8, f));
     }
     uint32_t bounds[SLICES + 1], pbounds[SLICES + 1];  // slice boundaries in sort tiles / pack tiles
     for (int q = 0; q <= ns; q++) {
@@ -709,6 +709,7 @@ int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const v
     g.pack_tiles = (uint32_t)((npix + PACK_TILE - 1) / PACK_TILE);
     g.color = (uint32_t)color;
     g.depth = (uint32_t)depth;
+    g.nctx = planes == 3 ? nctx_of<int16_t>() : nctx_of<uint8_t>();  // (16-bit samples: run_wide has tables of its own)
     l.first_image = first;
     const uint8_t *src = (const uint8_t *)d_pixels + first * frame_bytes;
     l.d_planes = src;

@@ -10,8 +10,14 @@
 
 namespace felics {
 
-// u8 samples (and Y/Co/Cg of RGB8): contexts 0..510 (traits.rs:28), table padded to 512.
+// Contexts (H - L of a pixel's two neighbours, traits.rs:28): 0..255 for u8 samples, 0..510 for the Y/Co/Cg planes of
+// RGB8 (table padded to 512).  NCTX sizes what is shared by both (LDS tables, upper bounds); the per-tile count matrix,
+// the chain tables and the spine's grid use the sample type's own count, nctx_of<T>() = Geometry::nctx.
 constexpr uint32_t NCTX = 512;
+template <typename T>
+constexpr uint32_t nctx_of() {
+    return sizeof(T) == 1 ? 256u : 512u;  // T = sample type (u8 / i16) or event type (u8 / u16)
+}
 // pixels one wave partitions by context in the hist / scatter stages.  Equal to the pack tile: the pack stage
 // computes k for exactly its own tile's events (k_pack_k), one look-back per workgroup.
 constexpr uint32_t SORT_TILE = 4096;
@@ -58,6 +64,7 @@ struct Geometry {
     uint32_t sort_tiles;        // ceil(npix / SORT_TILE)
     uint32_t pack_tiles;        // ceil(npix / PACK_TILE)
     uint32_t color, depth;      // header fields
+    uint32_t nctx;              // contexts per plane: nctx_of<sample type>()
 };
 
 void launch_rgb8_to_planes(hipStream_t s, const uint8_t *rgb, int16_t *planes, uint32_t npix, uint32_t nimg);

@@ -85,17 +85,18 @@ __global__ __launch_bounds__(256) void k_rgb8_to_planes(const uint8_t *__restric
 
 // ------------------------------------------------------------------------------------------
 // hist: one wave per tile of SORT_TILE pixels; LDS histogram of event contexts.
-// counts[(plane*ntiles + tile)*NCTX + ctx]
+// counts[(plane*ntiles + tile)*nctx + ctx]
 // ------------------------------------------------------------------------------------------
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_hist(const T *__restrict__ planes, uint32_t *__restrict__ counts,
                                               uint32_t W, uint32_t npix, uint32_t ntiles) {
-    __shared__ uint32_t hist[4][NCTX];
+    __shared__ uint32_t hist[4][nctx_of<T>()];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t tile = blockIdx.x * 4 + wave;
     const uint32_t plane = blockIdx.y;
-    for (uint32_t c = lane; c < NCTX; c += 64) hist[wave][c] = 0;
+    constexpr uint32_t NC = nctx_of<T>();
+    for (uint32_t c = lane; c < NC; c += 64) hist[wave][c] = 0;
     __builtin_amdgcn_wave_barrier();
     if (tile < ntiles) {
         const T *pl = planes + (uint64_t)plane * npix;
@@ -155,8 +156,8 @@ __global__ __launch_bounds__(256) void k_hist(const T *__restrict__ planes, uint
             y0 = y1;
         }
         __builtin_amdgcn_wave_barrier();
-        uint32_t *dst = counts + ((uint64_t)plane * ntiles + tile) * NCTX;
-        for (uint32_t c = lane; c < NCTX; c += 64) dst[c] = hist[wave][c];
+        uint32_t *dst = counts + ((uint64_t)plane * ntiles + tile) * NC;
+        for (uint32_t c = lane; c < NC; c += 64) dst[c] = hist[wave][c];
     }
 }
 
@@ -171,42 +172,43 @@ __global__ __launch_bounds__(256) void k_hist(const T *__restrict__ planes, uint
 constexpr uint32_t OFF_SEGS = 8, OFF_CTX = 32;
 
 __global__ __launch_bounds__(OFF_SEGS *OFF_CTX) void k_tile_offsets(uint32_t *__restrict__ counts,
-                                                                    uint32_t *__restrict__ chain_len, uint32_t ntiles) {
+                                                                    uint32_t *__restrict__ chain_len, uint32_t ntiles,
+                                                                    uint32_t nctx) {
     __shared__ uint32_t seg_sum[OFF_SEGS][OFF_CTX];
     const uint32_t cl = threadIdx.x % OFF_CTX, seg = threadIdx.x / OFF_CTX;
     const uint32_t plane = blockIdx.y, c = blockIdx.x * OFF_CTX + cl;
     const uint32_t per = (ntiles + OFF_SEGS - 1) / OFF_SEGS;
     const uint32_t t0 = min(seg * per, ntiles), t1 = min(t0 + per, ntiles);
-    uint32_t *col = counts + (uint64_t)plane * ntiles * NCTX + c;
+    uint32_t *col = counts + (uint64_t)plane * ntiles * nctx + c;
     uint32_t sum = 0;
     uint32_t t = t0;
     for (; t + 8 <= t1; t += 8) {
         uint32_t v[8];
 #pragma unroll
-        for (uint32_t u = 0; u < 8; u++) v[u] = col[(uint64_t)(t + u) * NCTX];
+        for (uint32_t u = 0; u < 8; u++) v[u] = col[(uint64_t)(t + u) * nctx];
 #pragma unroll
         for (uint32_t u = 0; u < 8; u++) sum += v[u];
     }
-    for (; t < t1; t++) sum += col[(uint64_t)t * NCTX];
+    for (; t < t1; t++) sum += col[(uint64_t)t * nctx];
     seg_sum[seg][cl] = sum;
     __syncthreads();
     uint32_t run = 0;
     for (uint32_t q = 0; q < seg; q++) run += seg_sum[q][cl];
-    if (seg == OFF_SEGS - 1) chain_len[plane * NCTX + c] = run + sum;
+    if (seg == OFF_SEGS - 1) chain_len[plane * nctx + c] = run + sum;
     t = t0;
     for (; t + 8 <= t1; t += 8) {  // eight independent loads in flight, then the running sum
         uint32_t v[8];
 #pragma unroll
-        for (uint32_t u = 0; u < 8; u++) v[u] = col[(uint64_t)(t + u) * NCTX];
+        for (uint32_t u = 0; u < 8; u++) v[u] = col[(uint64_t)(t + u) * nctx];
 #pragma unroll
         for (uint32_t u = 0; u < 8; u++) {
-            col[(uint64_t)(t + u) * NCTX] = run;
+            col[(uint64_t)(t + u) * nctx] = run;
             run += v[u];
         }
     }
     for (; t < t1; t++) {
-        const uint32_t v = col[(uint64_t)t * NCTX];
-        col[(uint64_t)t * NCTX] = run;
+        const uint32_t v = col[(uint64_t)t * nctx];
+        col[(uint64_t)t * nctx] = run;
         run += v;
     }
 }
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
                                                  uint32_t tile_end) {
     constexpr uint32_t RING = 512;  // a trip adds at most 256 events to fewer than 64 left over
     static_assert(SORT_TILE <= (1u << 13), "ring records keep the pixel's offset in its tile in 13 bits");
-    __shared__ uint32_t runs[4][NCTX];
+    __shared__ uint32_t runs[4][nctx_of<T>()];
     __shared__ uint32_t rings[4][RING];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t tile = tile_begin + blockIdx.x * 4 + wave;
@@ -278,9 +280,10 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
     if (tile >= tile_end) return;
     uint32_t *run = runs[wave];
     {
-        const uint32_t *off = tile_off + ((uint64_t)plane * ntiles + tile) * NCTX;
-        const uint32_t *cb = chain_base + (uint64_t)plane * NCTX;
-        for (uint32_t c = lane; c < NCTX; c += 64) run[c] = off[c] + cb[c];
+        constexpr uint32_t NC = nctx_of<T>();
+        const uint32_t *off = tile_off + ((uint64_t)plane * ntiles + tile) * NC;
+        const uint32_t *cb = chain_base + (uint64_t)plane * NC;
+        for (uint32_t c = lane; c < NC; c += 64) run[c] = off[c] + cb[c];
     }
     __builtin_amdgcn_wave_barrier();
     const T *pl = planes + (uint64_t)plane * npix;
@@ -434,9 +437,10 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
     // Workgroup w -> (context w / nplanes, plane w % nplanes): the long chains (small contexts) of all
     // planes start first and land on different XCDs (workgroups are dealt round-robin over the XCDs).
     if (blockIdx.x >= nchains) return;
-    const uint32_t nplanes = nchains / NCTX;
+    constexpr uint32_t NC = nctx_of<ET>();
+    const uint32_t nplanes = nchains / NC;
     const uint32_t ctx = blockIdx.x / nplanes, plane = blockIdx.x % nplanes;
-    const uint32_t chain = plane * NCTX + ctx;
+    const uint32_t chain = plane * NC + ctx;
     const uint32_t n = chain_len[chain];
     if (n == 0) return;
     const uint32_t lane = lane_id();
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
     // scattered: it resumes every chain at chain_prog and stops at the last whole block whose events
     // all come from tiles < t_end (the final launch, t_end = ntiles, also takes the partial block).
     const bool final_slice = t_end >= ntiles;
-    const uint32_t avail = final_slice ? n : tile_off[((uint64_t)plane * ntiles + t_end) * NCTX + ctx];  // events in place
+    const uint32_t avail = final_slice ? n : tile_off[((uint64_t)plane * ntiles + t_end) * NC + ctx];  // events in place
     const uint32_t nblocks = final_slice ? (n + 63u) >> 6 : avail >> 6;
     uint32_t *prog = chain_prog + (uint64_t)chain * 8;  // [0] next block, [1..6] state
     const uint32_t first_block = prog[0];
@@ -1503,20 +1507,21 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     constexpr uint32_t NWV = PACK_THREADS / 64;
     // ---- k of this sort tile's events.  The 64-event blocks that overlap the tile's runs are listed in LDS first
-    // (thread t lists the blocks of contexts t and t + 256; the list lives in the bit window and the private bit
+    // (thread t lists the blocks of context t -- and t + 256 for Y/Co/Cg planes; the list lives in the bit window and the private bit
     // buffers, which the pack stage only uses afterwards) and then dealt to the waves one by one: a synthetic or
     // smooth frame has ten contexts that matter, so dealing whole contexts leaves one wave with a third more blocks
     // than the average.  (Listing the runs instead and letting every wave walk that list with scalar code was measured:
     // what the listing saves, the walk costs.)
     {
-        const uint32_t *off0 = ks.tile_off + ((uint64_t)plane * ks.sort_ntiles + st) * NCTX;
+        constexpr uint32_t NC = nctx_of<T>();
+        const uint32_t *off0 = ks.tile_off + ((uint64_t)plane * ks.sort_ntiles + st) * NC;
         const bool last_tile = st + 1 == ks.sort_ntiles;
-        const uint32_t *off1 = last_tile ? ks.chain_len + (uint64_t)plane * NCTX : off0 + NCTX;
-        const uint32_t *cb = ks.chain_base + (uint64_t)plane * NCTX;
+        const uint32_t *off1 = last_tile ? ks.chain_len + (uint64_t)plane * NC : off0 + NC;
+        const uint32_t *cb = ks.chain_base + (uint64_t)plane * NC;
         const ET *sorted_e = reinterpret_cast<const ET *>(ks.sorted_e);
-        constexpr uint32_t CPT = NCTX / PACK_THREADS;  // contexts per thread
-        static_assert(NCTX == CPT * PACK_THREADS, "thread t lists contexts t, t + PACK_THREADS, ...");
-        constexpr uint32_t MAX_ITEMS = SORT_TILE / 64 + 2 * NCTX;  // a run of L events touches at most L / 64 + 2 blocks
+        constexpr uint32_t CPT = NC / PACK_THREADS;  // contexts per thread
+        static_assert(NC == CPT * PACK_THREADS, "thread t lists contexts t, t + PACK_THREADS, ...");
+        constexpr uint32_t MAX_ITEMS = SORT_TILE / 64 + 2 * NC;  // a run of L events touches at most L / 64 + 2 blocks
         static_assert(2 * MAX_ITEMS <= FUSED_WIN_WORDS + LOCAL_WORDS * PACK_THREADS && offsetof(FusedLDS, lbuf) == offsetof(FusedLDS, win) + sizeof(fl.win),
                       "the block list borrows win + lbuf");
         uint2 *items = reinterpret_cast<uint2 *>(fl.win);  // {block, first lane of the run | lanes with an event in place << 8}
@@ -1685,9 +1690,9 @@ template void launch_hist<int16_t>(hipStream_t, const int16_t *, uint32_t *, con
 
 void launch_offsets(hipStream_t s, uint32_t *counts, uint32_t *chain_len, uint32_t *chain_base,
                     uint32_t *total_events, const Geometry &g) {
-    const uint32_t nchains = g.nplanes * NCTX;
-    FELICS_LAUNCH(k_tile_offsets, dim3(NCTX / OFF_CTX, g.nplanes), dim3(OFF_SEGS * OFF_CTX), s, counts, chain_len,
-                       g.sort_tiles);
+    const uint32_t nchains = g.nplanes * g.nctx;
+    FELICS_LAUNCH(k_tile_offsets, dim3(g.nctx / OFF_CTX, g.nplanes), dim3(OFF_SEGS * OFF_CTX), s, counts, chain_len,
+                       g.sort_tiles, g.nctx);
     FELICS_LAUNCH(k_chain_bases, dim3(1), dim3(1024), s, chain_len, chain_base, nchains, total_events);
 }
 
@@ -1710,7 +1715,7 @@ template void launch_scatter<int16_t, uint16_t>(hipStream_t, const int16_t *, co
 template <typename ET>
 void launch_zero_padding(hipStream_t s, ET *sorted_e, uint32_t *pix_of, const uint32_t *chain_base,
                          const uint32_t *chain_len, const Geometry &g) {
-    const uint32_t nchains = g.nplanes * NCTX;
+    const uint32_t nchains = g.nplanes * g.nctx;
     FELICS_LAUNCH((k_zero_padding<ET>), dim3(cdiv(nchains, 256)), dim3(256), s, sorted_e, pix_of, chain_base,
                        chain_len, nchains);
 }
@@ -1723,7 +1728,7 @@ template <typename ET>
 void launch_spine(hipStream_t s, const ET *sorted_e, uint32_t *block_state, const uint32_t *chain_base,
                   const uint32_t *chain_len, const uint32_t *tile_off, uint32_t t_end, uint32_t *chain_prog,
                   uint32_t *block_tag, uint32_t *partial, uint32_t epoch, uint32_t slice, const Geometry &g) {
-    const uint32_t nchains = g.nplanes * NCTX;
+    const uint32_t nchains = g.nplanes * g.nctx;
     FELICS_LAUNCH((k_spine<ET>), dim3(nchains), dim3(64), s, sorted_e, block_state, chain_base, chain_len,
                        nchains, tile_off, g.sort_tiles, t_end, chain_prog, block_tag,
                        reinterpret_cast<uint2 *>(partial) + (uint64_t)(slice - 1) * nchains,
@@ -1741,7 +1746,7 @@ void launch_assign(hipStream_t s, const ET *sorted_e, const uint32_t *pix_of, ui
                    const uint32_t *block_state, const uint32_t *total_slots, const uint32_t *block_tag,
                    const uint32_t *partial, uint32_t epoch, uint32_t slice, const Geometry &g) {
     // persistent: 8 workgroups of 4 waves per CU walk all tags (fewer if there cannot be that many blocks)
-    const uint32_t nchains = g.nplanes * NCTX;
+    const uint32_t nchains = g.nplanes * g.nctx;
     const uint32_t max_blocks = max_event_blocks(g);
     const uint32_t wgs = std::min<uint32_t>(cdiv(max_blocks, 4 * 64), 256u * 8u);
     FELICS_LAUNCH((k_assign<ET>), dim3(wgs), dim3(256), s, sorted_e, block_state, pix_of, k_map, total_slots,

@@ -1,0 +1,40 @@
+"""Where a pack_k workgroup's time goes, phase by phase (s_memtime stamps of thread 0, summed per tile).
+
+Needs a library built with the stamps compiled in (they are not in the product build):
+    make -C felics_amd/csrc lib OUT=../../scratch/pstamps CXXFLAGS="-O3 -std=c++17 -fPIC -DFELICS_PACK_STAMPS"
+    python profiles/tools/pack_stamps.py 64        # on the GPU box, from the repository root
+"""
+import os, sys, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("FELICS_LIB_PATH", os.path.join(ROOT, "scratch", "pstamps", "libfelics.so"))
+import numpy as np, torch
+import felics_amd
+from felics_amd import synth_torch, api
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+W, H = 3840, 2160
+frames = torch.stack([synth_torch.gray8(W, H, f, "S1") for f in range(n)])
+d_out = torch.empty(int(n * W * H * 1.25) + (1 << 20), dtype=torch.uint8, device="cuda")
+torch.cuda.synchronize()
+enc = felics_amd.Encoder(0)
+lib = ctypes.CDLL(os.environ["FELICS_LIB_PATH"])
+buf = (ctypes.c_ulonglong * (256 * 16))()
+import time
+for _ in range(3):
+    enc.compress_batch_device(frames.data_ptr(), n, W, H, 0, 0, d_out.data_ptr(), d_out.numel())
+lib.felics_debug_pack_stamps(buf, 1)
+t = time.time()
+R = 5
+for _ in range(R):
+    enc.compress_batch_device(frames.data_ptr(), n, W, H, 0, 0, d_out.data_ptr(), d_out.numel())
+dt = (time.time() - t) / R
+lib.felics_debug_pack_stamps(buf, 0)
+a = np.array(list(buf), dtype=np.float64).reshape(256, 16); v = list(a.sum(0))
+cnt = v[15]
+names = ["ticket", "items: expansion + barrier", "own assign loop", "wait other waves", "stage pixels", "phase 1 (codes)", "sync", "look-back + sync", "phase 2 (window, stores)", "items: loads + staging", "items: scan + barrier"]
+print("blocking call %.3f ms; %d tiles stamped; s_memtime ticks per tile (thread 0):" % (dt * 1e3, cnt))
+tot = sum(v[:11])
+for i, nm in enumerate(names):
+    print("  %-26s %9.0f  %5.1f %%" % (nm, v[i] / cnt, 100.0 * v[i] / tot))
+print("  total %.0f ticks per tile" % (tot / cnt))
+enc.close()

@@ -6,9 +6,11 @@
 // before it, and the planes of an RGB image share one bit stream (compression.rs:385-400: plane c + 1
 // starts at the bit plane c ended on).  The only parallelism the format offers is ACROSS streams, so:
 // one wave per stream, the estimator table (512 rows of six counters, 12 KiB) and the two image rows the
-// neighbour rule looks at in LDS, the stream pulled through LDS 256 bytes at a time with coalesced
-// loads, finished rows stored coalesced.  A batch fills the chip from about a thousand streams up; a
-// single stream runs at the speed of one lane.
+// neighbour rule looks at in LDS, the stream pulled in 256 bytes at a time with coalesced loads, finished
+// rows stored coalesced.  A batch fills the chip from about a thousand streams up; a single stream runs at
+// the speed of one wave's instruction stream: ~1 250 cycles per pixel, whether that stream is vector code
+// (round 2's first form: 112 MPix/s for 64 streams) or, as now, scalar code (122 MPix/s) -- a lone wave
+// issues an instruction of either kind about every ten cycles and pays more for every taken branch.
 //
 // Valid streams decode to exactly the pixels the host decoder (felics_decode.cpp) produces.  Corrupt
 // streams end with an error status (the code can differ from the host decoder's where both a range and a
@@ -23,108 +25,92 @@
 
 namespace felics {
 
+// samples of an LDS row: whole 64-sample blocks (a block of the row above is read with one vector load)
+__host__ __device__ static inline uint32_t decode8_row_stride(uint32_t W) { return (W + 63u) & ~63u; }
+
 namespace {
 
-constexpr uint32_t CHUNK_DW = 64;  // dwords of the stream staged in LDS at a time
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int unii(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // MSB-first bit reader over [base, base + len) in global memory (bitstream-io BitReader<_, BigEndian>).
-// Wave-uniform: every lane holds the same state; the 64 lanes only differ when they fetch a chunk.
-struct WaveBits {
-    const uint8_t *base;   // first byte of the bit stream
-    uint64_t len;          // bytes
-    uint64_t next_byte;    // offset of the next byte to stage (multiple of 4 relative to the aligned base)
-    const uint32_t *al;    // aligned-down dword pointer of `base`
-    uint32_t skew;         // base - al, bytes (0..3)
-    uint32_t *chunk;       // LDS, CHUNK_DW dwords
-    uint32_t pos;          // next dword of the chunk to consume
-    uint32_t have;         // dwords in the chunk
+// Everything about the position is wave-uniform and lives in scalar registers; the stream itself sits in two vector
+// registers (lane j = dword j of a 256-byte chunk, big-endian order restored; the chunk after it already asked for),
+// and the next dword is picked out of them with v_readlane: no LDS and no memory wait on the per-pixel path.
+struct ScalarBits {
+    const uint32_t *al;    // aligned-down dword pointer of the stream's first byte
+    uint64_t total_dw;     // dwords from `al` that hold stream bytes
+    uint64_t chunk0;       // dword index of cur's lane 0
+    uint32_t cur, nxt;     // VECTOR: this chunk and the next one (zeros past the end)
+    uint32_t cpos;         // next dword of `cur` to consume, 0..64
     uint64_t acc;          // unread bits, left-aligned
     uint32_t navail;       // valid bits in acc
-    uint64_t consumed;     // bits handed out so far
-    bool failed;           // read past the end (DecompressionError::IoError)
+    int64_t bits_left;     // stream bits not handed out yet; negative = read past the end (DecompressionError::IoError)
 
-    __device__ __forceinline__ void init(const uint8_t *p, uint64_t n, uint32_t *lds) {
-        base = p;
-        len = n;
-        skew = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u);
+    __device__ __forceinline__ uint32_t fetch(uint64_t first) const {
+        const uint64_t i = first + lane_id();
+        return i < total_dw ? __builtin_bswap32(al[i]) : 0u;
+    }
+    __device__ __forceinline__ void init(const uint8_t *p, uint64_t n) {
+        const uint32_t skew = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u);
         al = reinterpret_cast<const uint32_t *>(p - skew);
-        next_byte = 0;
-        chunk = lds;
-        pos = have = 0;
+        total_dw = (skew + n + 3u) >> 2;
+        chunk0 = 0;
+        cur = fetch(0);
+        nxt = fetch(64);
+        cpos = 0;
         acc = 0;
         navail = 0;
-        consumed = 0;
-        failed = false;
-        // the first dword may start before the stream: drop the skew bytes
+        bits_left = (int64_t)(n * 8u);
         refill();
-        if (skew) {
+        if (skew) {  // the first dword starts before the stream: drop those bytes
             acc <<= 8u * skew;
             navail -= 8u * skew;
         }
     }
-    __device__ __forceinline__ void stage() {  // next CHUNK_DW aligned dwords -> LDS (zero past the end)
-        const uint32_t lane = lane_id();
-        const uint64_t total_dw = (skew + len + 3u) >> 2;
-        const uint64_t first = next_byte >> 2;
-        __builtin_amdgcn_wave_barrier();
-        uint32_t v = 0;
-        if (first + lane < total_dw) v = al[first + lane];
-        chunk[lane] = __builtin_bswap32(v);  // big-endian bit order: first byte on top
-        __builtin_amdgcn_wave_barrier();
-        have = (uint32_t)(total_dw - first < CHUNK_DW ? total_dw - first : CHUNK_DW);
-        pos = 0;
-        next_byte += (uint64_t)CHUNK_DW * 4u;
-    }
-    __device__ __forceinline__ void refill() {  // keep at least 32 bits in acc (zeros past the end)
-        while (navail <= 32) {
-            if (pos == have) {
-                if (have != 0 && have < CHUNK_DW) {  // the stream is exhausted: feed zeros
-                    navail += 32;
-                    continue;
-                }
-                stage();
-                if (have == 0) {
-                    have = 1;  // nothing left at all: one dword of zeros per call from here on
-                    chunk[0] = 0;
-                }
+    // at least 33 valid bits in acc afterwards (zeros past the end of the stream)
+    __device__ __forceinline__ void refill() {
+        if (navail <= 32u) {
+            if (cpos == 64u) {
+                cur = nxt;
+                chunk0 += 64u;
+                nxt = fetch(chunk0 + 64u);
+                cpos = 0;
             }
-            acc |= (uint64_t)chunk[pos++] << (32u - navail);
-            navail += 32;
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)cpos);
+            cpos++;
+            acc |= (uint64_t)w << (32u - navail);
+            navail += 32u;
         }
     }
-    __device__ __forceinline__ uint32_t get(uint32_t n) {  // n <= 32
-        if (n == 0) return 0;
-        refill();
-        const uint32_t v = (uint32_t)(acc >> (64u - n));
+    // the next n <= 32 bits; the caller has refilled (n <= navail)
+    __device__ __forceinline__ uint32_t take(uint32_t n) {
+        const uint32_t v = n ? (uint32_t)(acc >> (64u - n)) : 0u;
         acc <<= n;
         navail -= n;
-        consumed += n;
-        if (consumed > len * 8u) failed = true;
+        bits_left -= n;
         return v;
     }
-    __device__ __forceinline__ uint64_t unary0() {  // ones before the first zero (read_unary0)
+    __device__ __forceinline__ uint32_t get(uint32_t n) {
+        refill();
+        return take(n);
+    }
+    __device__ __forceinline__ bool failed() const { return bits_left < 0; }
+    // ones before the first zero, the zero consumed (read_unary0)
+    __device__ __forceinline__ uint64_t unary0() {
         uint64_t q = 0;
         while (true) {
             refill();
             const uint32_t top = (uint32_t)(acc >> 32);
-            const uint32_t ones = top == 0xFFFFFFFFu ? 32u : (uint32_t)__clz((int)~top);
-            if (ones == 32) {
-                q += 32;
-                acc <<= 32;
-                navail -= 32;
-                consumed += 32;
-                if (consumed > len * 8u) {
-                    failed = true;
-                    return q;
-                }
+            const uint32_t ones = top == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_clz(~top);
+            if (ones == 32u) {
+                q += 32u;
+                take(32u);
+                if (failed()) return q;
                 continue;
             }
-            q += ones;
-            acc <<= ones + 1;
-            navail -= ones + 1;
-            consumed += ones + 1;
-            if (consumed > len * 8u) failed = true;
-            return q;
+            take(ones + 1u);
+            return q + ones;
         }
     }
 };
@@ -133,7 +119,14 @@ struct WaveBits {
 
 // One wave per stream.  status[i] = FELICS_OK or an error code.  Gray: u8 pixels straight to `pixels`;
 // RGB: the three planes as int16 to `planes` (image i at i * 3 * npix), converted by k_ycocg8_to_rgb.
-// LDS (dynamic): table 512 x 6 u32 | rows 2 x (W + 2) i16 | chunk.
+// LDS (dynamic): table 512 x 6 u32 | rows 2 x rstride i16.
+//
+// The decode loop is one pixel after the other, and a lone wave retires a dependent vector instruction every ~10
+// cycles: the per-pixel path is therefore written so that the compiler keeps it in SCALAR registers and instructions
+// (every value that comes out of LDS or a vector register passes through readfirstlane / readlane, nothing depends on
+// the lane id).  The vector side only moves data in bulk: the stream 256 bytes at a time, the row above 64 samples at
+// a time (one register, read with v_readlane), the decoded row 64 samples at a time (collected with v_writelane,
+// stored to LDS for the next row and to global memory coalesced).
 __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ streams, const uint64_t *__restrict__ offsets,
                                                 const uint64_t *__restrict__ lens, uint32_t W, uint32_t H, uint32_t color,
                                                 uint8_t *__restrict__ pixels, int16_t *__restrict__ planes,
@@ -141,8 +134,7 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *table = reinterpret_cast<uint32_t *>(smem);
     int16_t *rows = reinterpret_cast<int16_t *>(smem + NCTX * 6 * 4);
-    const uint32_t rstride = (W + 2u + 1u) & ~1u;
-    uint32_t *chunk = reinterpret_cast<uint32_t *>(smem + NCTX * 6 * 4 + 2u * rstride * 2u);
+    const uint32_t rstride = decode8_row_stride(W);
     const uint32_t img = blockIdx.x, lane = lane_id();
     const uint8_t *s = streams + offsets[img];
     const uint64_t slen = lens[img];
@@ -160,15 +152,16 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
         else if (s[5] > 1) rc = FELICS_E_INVALID_PIXEL_DEPTH;
         else if (s[4] != color || s[5] != 0 || w != W || h != H) rc = FELICS_E_INVALID_DIMENSIONS;
     }
+    rc = unii(rc);
     if (rc != FELICS_OK) {
         if (lane == 0) status[img] = rc;
         return;
     }
-    WaveBits br;
-    br.init(s + FELICS_HEADER_BYTES, slen - FELICS_HEADER_BYTES, chunk);
+    ScalarBits br;
+    br.init(s + FELICS_HEADER_BYTES, slen - FELICS_HEADER_BYTES);
     for (uint32_t c = 0; c < nplanes && rc == FELICS_OK; c++) {
         const int32_t p0 = (int32_t)br.get(32), p1 = (int32_t)br.get(32);  // compression.rs:166-167
-        if (br.failed) {
+        if (br.failed()) {
             rc = FELICS_E_IO;
             break;
         }
@@ -178,29 +171,24 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
         int16_t *outp = planes ? planes + ((uint64_t)img * nplanes + c) * npix : nullptr;
         uint8_t *outg = planes ? nullptr : pixels + (uint64_t)img * npix;
         const int lo_ok = color ? -255 : 0, hi_ok = 255;  // what a sample of this plane can be (Y 0..255, Co / Cg -255..255)
-        // rows: cur = rows + (y & 1) * rstride, prev the other; row y is stored when it is complete
+        // rows: cur = the row being decoded, prev = the one above; both in LDS, written 64 samples at a time
         uint32_t x = 0, y = 0;
         int16_t *cur = rows, *prev = rows + rstride;
-        auto flush_row = [&](uint32_t yy, const int16_t *r) {
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t xx = lane; xx < W; xx += 64) {
-                if (outg)
-                    outg[(uint64_t)yy * W + xx] = (uint8_t)r[xx];
-                else
-                    outp[(uint64_t)yy * W + xx] = r[xx];
-            }
-            __builtin_amdgcn_wave_barrier();
-        };
-        // The pixel to the left and the one before it stay in registers; the sample above the NEXT pixel is fetched
-        // while this one is decoded, so its LDS latency is off the serial path.
-        int left = 0, left2 = 0, up_next = 0;
+        int upv = 0;   // VECTOR: prev[xb + lane] for the 64-sample block xb the walk stands in
+        int rowv = 0;  // VECTOR: the samples of this block decoded so far
+        int left = 0, left2 = 0;
+        int first_col2 = 0;  // cur[0] as it was before this row: the sample two rows up (first-column rule)
         for (uint64_t i = 0; i < npix; i++) {
+            const uint32_t xl = x & 63u;
+            if (xl == 0) {
+                if (y > 0) upv = (int)prev[x + lane];  // (rows are padded to whole blocks)
+                if (x == 0 && y >= 2) first_col2 = unii((int)cur[0]);
+            }
             int pv;
-            const int above = up_next;
-            if (y > 0 && x + 1 < W) up_next = prev[x + 1];
             if (i < 2) {
                 pv = i == 0 ? p0 : p1;
             } else {
+                const int above = __builtin_amdgcn_readlane(upv, (int)xl);
                 int v1, v2;  // misc.rs:6-24
                 if (x > 0 && y > 0) {
                     v1 = left;
@@ -208,36 +196,38 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
                 } else if (y == 0) {
                     v1 = left;
                     v2 = left2;
-                } else if (y >= 2) {  // first column: above and two rows up (the row `cur` still holds: it was row y - 2)
+                } else if (y >= 2) {  // first column: above and two rows up
                     v1 = above;
-                    v2 = cur[0];
+                    v2 = first_col2;
                 } else {  // pixel (0,1): above and above-right
                     v1 = above;
-                    v2 = prev[1];
+                    v2 = W > 1 ? __builtin_amdgcn_readlane(upv, 1) : 0;
                 }
                 const int hi = max(v1, v2), lo = min(v1, v2);
                 const uint32_t ctx = (uint32_t)(hi - lo);  // <= 510 because every stored sample is in range
-                if (br.get(1)) {  // in range: phased-in code of p - L (phase_in_coding.rs:86-112)
+                br.refill();  // >= 33 bits: an in-range code has at most 11, the two flags of the other kind 2
+                if (br.take(1)) {  // in range: phased-in code of p - L (phase_in_coding.rs:86-112)
                     const uint32_t n = ctx + 1;
-                    const uint32_t m = 31u - (uint32_t)__clz((int)n);
+                    const uint32_t m = 31u - (uint32_t)__builtin_clz(n);
                     const uint32_t right_p = (2u << m) - n, left_p = n - (1u << m);
-                    uint32_t r = br.get(m);
-                    if (r >= right_p) r = (r - right_p) * 2u + right_p + br.get(1);
+                    uint32_t r = br.take(m);
+                    if (r >= right_p) r = (r - right_p) * 2u + right_p + br.take(1);
                     uint32_t rot = r + left_p;  // rotate_left: (r + left_p) mod n, r < n
                     if (rot >= n) rot -= n;
                     pv = lo + (int)rot;
                 } else {
-                    const bool above_flag = br.get(1) != 0;
-                    uint64_t *row = reinterpret_cast<uint64_t *>(table + ctx * 6);  // 24-byte rows: 8-byte aligned
-                    const uint64_t r01 = row[0], r23 = row[1], r45 = row[2];     // one LDS round trip for the row
-                    uint32_t S[6] = {(uint32_t)r01, (uint32_t)(r01 >> 32), (uint32_t)r23, (uint32_t)(r23 >> 32), (uint32_t)r45, (uint32_t)(r45 >> 32)};
+                    const bool above_flag = br.take(1) != 0;
+                    const uint64_t *row = reinterpret_cast<const uint64_t *>(table + ctx * 6);  // 24-byte rows: 8-byte aligned
+                    const uint64_t r01 = row[0], r23 = row[1], r45 = row[2];                 // one LDS round trip for the row
+                    uint32_t S[6] = {uni((uint32_t)r01), uni((uint32_t)(r01 >> 32)), uni((uint32_t)r23),
+                                     uni((uint32_t)(r23 >> 32)), uni((uint32_t)r45), uni((uint32_t)(r45 >> 32))};
                     // get_k: smallest counter, ties to the largest k (parameter_selection.rs:71-85)
                     const uint32_t key = min(min(min((S[0] << 3) | 7u, (S[1] << 3) | 6u), min((S[2] << 3) | 5u, (S[3] << 3) | 4u)),
                                              min((S[4] << 3) | 3u, (S[5] << 3) | 2u));
                     const uint32_t k = 7u - (key & 7u);
                     const uint64_t q = br.unary0();
                     const uint64_t e64 = (q << k) + br.get(k);
-                    if (br.failed) {
+                    if (br.failed()) {
                         rc = FELICS_E_IO;
                         break;
                     }
@@ -253,14 +243,13 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
                         mn = min(mn, S[kk]);
                     }
                     const uint32_t hsh = mn > 1024u ? 1u : 0u;
-                    if (lane == 0) {
-                        row[0] = (uint64_t)(S[0] >> hsh) | ((uint64_t)(S[1] >> hsh) << 32);
-                        row[1] = (uint64_t)(S[2] >> hsh) | ((uint64_t)(S[3] >> hsh) << 32);
-                        row[2] = (uint64_t)(S[4] >> hsh) | ((uint64_t)(S[5] >> hsh) << 32);
-                    }
+                    uint64_t *wrow = reinterpret_cast<uint64_t *>(table + ctx * 6);  // (every lane: same address, same value)
+                    wrow[0] = (uint64_t)(S[0] >> hsh) | ((uint64_t)(S[1] >> hsh) << 32);
+                    wrow[1] = (uint64_t)(S[2] >> hsh) | ((uint64_t)(S[3] >> hsh) << 32);
+                    wrow[2] = (uint64_t)(S[4] >> hsh) | ((uint64_t)(S[5] >> hsh) << 32);
                     pv = above_flag ? hi + (int)e + 1 : lo - (int)e - 1;
                 }
-                if (br.failed) {
+                if (br.failed()) {
                     rc = FELICS_E_IO;
                     break;
                 }
@@ -269,17 +258,29 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
                 rc = FELICS_E_INVALID_VALUE;
                 break;
             }
-            if (lane == 0) cur[x] = (int16_t)pv;
+            rowv = lane == xl ? pv : rowv;  // (off the serial path: nothing reads rowv before the block is complete)
             left2 = left;
             left = pv;
-            if (++x == W) {
-                flush_row(y, cur);  // (its wave barriers also order the row's writes before the next row reads them)
+            const bool row_end = x + 1 == W;
+            if (xl == 63u || row_end) {  // a block of the row is complete: to LDS (the next row's `above`) and to the output
+                const uint32_t xb = x & ~63u;
+                if (xb + lane <= x) {
+                    cur[xb + lane] = (int16_t)rowv;
+                    if (outg)
+                        outg[(uint64_t)y * W + xb + lane] = (uint8_t)rowv;
+                    else
+                        outp[(uint64_t)y * W + xb + lane] = (int16_t)rowv;
+                }
+            }
+            if (row_end) {
+                __builtin_amdgcn_wave_barrier();
                 x = 0;
                 y++;
                 int16_t *t = cur;
                 cur = prev;
                 prev = t;
-                up_next = prev[0];
+            } else {
+                x++;
             }
         }
     }
@@ -306,10 +307,7 @@ __global__ __launch_bounds__(256) void k_ycocg8_to_rgb(const int16_t *__restrict
     if (bad) atomicCAS(&status[img], FELICS_OK, FELICS_E_INVALID_VALUE);
 }
 
-uint32_t decode8_lds_bytes(uint32_t W) {
-    const uint32_t rstride = (W + 2u + 1u) & ~1u;
-    return NCTX * 6 * 4 + 2u * rstride * 2u + CHUNK_DW * 4u;
-}
+uint32_t decode8_lds_bytes(uint32_t W) { return NCTX * 6 * 4 + 2u * decode8_row_stride(W) * 2u; }
 
 hipError_t launch_decode8(hipStream_t s, const uint8_t *streams, const uint64_t *offsets, const uint64_t *lens, uint32_t n,
                           uint32_t W, uint32_t H, uint32_t color, uint8_t *pixels, int16_t *planes, int *status) {

@@ -1204,7 +1204,7 @@ int felics_decompress_batch_device(felics_ctx *ctx, size_t n, const void *d_stre
     const uint64_t frame_bytes = npix * planes * bps;
     if (frame_bytes * n > d_pixels_cap) return FELICS_E_BUFFER_TOO_SMALL;
     if (frame_bytes && !d_pixels) return FELICS_E_INVALID_ARGUMENT;
-    if (bps == 2 || decode8_lds_bytes(hdr.width) > STRIPE_LDS_LIMIT) {
+    if (bps == 2 || decode8_lds_bytes(hdr.width, hdr.color_type) > STRIPE_LDS_LIMIT) {
         // host decoder, stream by stream
         std::vector<uint8_t> sbuf, pbuf((size_t)frame_bytes);
         int first_rc = FELICS_OK;

@@ -119,7 +119,7 @@ struct ScalarBits {
 
 // One wave per stream.  status[i] = FELICS_OK or an error code.  Gray: u8 pixels straight to `pixels`;
 // RGB: the three planes as int16 to `planes` (image i at i * 3 * npix), converted by k_ycocg8_to_rgb.
-// LDS (dynamic): table 512 x 6 u32 | rows 2 x rstride i16.
+// LDS (dynamic): table (256 or 512) x 6 u32 | rows 2 x rstride i16.
 //
 // The decode loop is one pixel after the other, and a lone wave retires a dependent vector instruction every ~10
 // cycles: the per-pixel path is therefore written so that the compiler keeps it in SCALAR registers and instructions
@@ -133,7 +133,8 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
                                                 int *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *table = reinterpret_cast<uint32_t *>(smem);
-    int16_t *rows = reinterpret_cast<int16_t *>(smem + NCTX * 6 * 4);
+    const uint32_t nctx = color ? nctx_of<int16_t>() : nctx_of<uint8_t>();  // gray: contexts 0..255, half the table
+    int16_t *rows = reinterpret_cast<int16_t *>(smem + nctx * 6 * 4);
     const uint32_t rstride = decode8_row_stride(W);
     const uint32_t img = blockIdx.x, lane = lane_id();
     const uint8_t *s = streams + offsets[img];
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
             break;
         }
         if (npix == 0) continue;
-        for (uint32_t i = lane; i < NCTX * 6; i += 64) table[i] = 0;  // KEstimator::new
+        for (uint32_t i = lane; i < nctx * 6; i += 64) table[i] = 0;  // KEstimator::new
         __builtin_amdgcn_wave_barrier();
         int16_t *outp = planes ? planes + ((uint64_t)img * nplanes + c) * npix : nullptr;
         uint8_t *outg = planes ? nullptr : pixels + (uint64_t)img * npix;
@@ -307,12 +308,14 @@ __global__ __launch_bounds__(256) void k_ycocg8_to_rgb(const int16_t *__restrict
     if (bad) atomicCAS(&status[img], FELICS_OK, FELICS_E_INVALID_VALUE);
 }
 
-uint32_t decode8_lds_bytes(uint32_t W) { return NCTX * 6 * 4 + 2u * decode8_row_stride(W) * 2u; }
+uint32_t decode8_lds_bytes(uint32_t W, uint32_t color) {
+    return (color ? nctx_of<int16_t>() : nctx_of<uint8_t>()) * 6 * 4 + 2u * decode8_row_stride(W) * 2u;
+}
 
 hipError_t launch_decode8(hipStream_t s, const uint8_t *streams, const uint64_t *offsets, const uint64_t *lens, uint32_t n,
                           uint32_t W, uint32_t H, uint32_t color, uint8_t *pixels, int16_t *planes, int *status) {
     if (n == 0) return hipSuccess;
-    const uint32_t lds = decode8_lds_bytes(W);
+    const uint32_t lds = decode8_lds_bytes(W, color);
     if (lds > 64u * 1024u) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode8),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)STRIPE_LDS_LIMIT);

@@ -233,7 +233,7 @@ void launch_join_edges_tiles(hipStream_t s, const uint64_t *tile_bitoff, const u
 
 // ---- GPU decoder for 8-bit streams (felics_gpudecode.hip): one wave per stream.  status[i] = FELICS_OK or an error
 // code; gray pixels go straight to `pixels`, RGB through int16 planes (image i at i * 3 * npix) + a conversion kernel.
-uint32_t decode8_lds_bytes(uint32_t W);
+uint32_t decode8_lds_bytes(uint32_t W, uint32_t color);
 hipError_t launch_decode8(hipStream_t s, const uint8_t *streams, const uint64_t *offsets, const uint64_t *lens, uint32_t n,
                           uint32_t W, uint32_t H, uint32_t color, uint8_t *pixels, int16_t *planes, int *status);
 

@@ -101,20 +101,26 @@ __device__ __forceinline__ void load4(const int16_t *__restrict__ p, int (&v)[4]
     v[0] = (int)(int16_t)w[0]; v[1] = (int)w[0] >> 16; v[2] = (int)(int16_t)w[1]; v[3] = (int)w[1] >> 16;
 }
 
-// Interior pixels of one image row (x > 0, y > 0 for all), four per lane: left and above from two wide loads.
+// 256 consecutive pixels of one image row below the first (y > 0), four per lane: left and above from two wide loads.
 // A wave covers 256 consecutive pixels (lane l: first + 4l ..), so the sample left of a lane's first pixel
-// is the last sample of the lane before it (one DPP wave shift); lane 0 fetches its own.
+// is the last sample of the lane before it (one DPP wave shift); lane 0 fetches its own -- and when the span starts in
+// the first column that "left" sample is the first-column rule's second neighbour instead (two rows up; above-right in
+// row 1: misc.rs:14-23), which is all that rule changes, the two neighbours being interchangeable (classify_values).
 // Split in two so that a caller can have the next trip's loads in flight while it works on this one.
+__device__ __forceinline__ uint32_t span_left_index(uint32_t first, uint32_t x, uint32_t y, uint32_t W) {
+    return x > 0 ? first - 1 : (y >= 2 ? first - 2 * W : first - W + 1);
+}
 struct Interior4 {
     int cur[4], up[4], left_lane0;
 };
 
 template <typename T>
-__device__ __forceinline__ void load_interior4(const T *__restrict__ pl, uint32_t first, uint32_t W, Interior4 &v) {
+__device__ __forceinline__ void load_interior4(const T *__restrict__ pl, uint32_t first, uint32_t W, uint32_t left_index,
+                                               Interior4 &v) {
     const uint32_t i = first + 4 * lane_id();
     load4(pl + i, v.cur);
     load4(pl + i - W, v.up);
-    v.left_lane0 = (int)pl[first - 1];  // same address in every lane: one scalar-like access
+    v.left_lane0 = (int)pl[left_index];  // span_left_index(); same address in every lane: one scalar-like access
 }
 
 __device__ __forceinline__ void classify_loaded4(const Interior4 &v, PixelClass (&pc)[4]) {
@@ -126,14 +132,14 @@ __device__ __forceinline__ void classify_loaded4(const Interior4 &v, PixelClass 
 }
 
 template <typename T>
-__device__ __forceinline__ void classify_interior4(const T *__restrict__ pl, uint32_t first, uint32_t W,
+__device__ __forceinline__ void classify_interior4(const T *__restrict__ pl, uint32_t first, uint32_t W, uint32_t left_index,
                                                    PixelClass (&pc)[4]) {
     const uint32_t i = first + 4 * lane_id();
     int cur[4], up[4];
     load4(pl + i, cur);
     load4(pl + i - W, up);
     int left0 = __builtin_amdgcn_update_dpp(0, cur[3], 0x138, 0xF, 0xF, false);  // wave_shr:1
-    if (lane_id() == 0) left0 = (int)pl[first - 1];
+    if (lane_id() == 0) left0 = (int)pl[left_index];
     pc[0] = classify_values(cur[0], left0, up[0]);
 #pragma unroll
     for (int j = 1; j < 4; j++) pc[j] = classify_values(cur[j], cur[j - 1], up[j]);

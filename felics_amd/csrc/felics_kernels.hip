@@ -107,11 +107,11 @@ __global__ __launch_bounds__(256) void k_hist(const T *__restrict__ planes, uint
         // row with x > 0, y > 0 -- nearly all of them -- takes the neighbour rule's interior case
         // without any per-pixel case analysis.
         uint32_t y0 = begin / W, x0 = begin - y0 * W;
-        auto is_interior = [&](uint32_t r, uint32_t x, uint32_t y) { return y > 0 && x > 0 && x + 256 <= W && r + 256 <= end; };
+        auto is_interior = [&](uint32_t r, uint32_t x, uint32_t y) { return y > 0 && x + 256 <= W && r + 256 <= end; };
         Interior4 nxt;
         bool have_nxt = false;  // the next trip's loads were issued during the trip before
         if (begin < end && is_interior(begin, x0, y0)) {
-            load_interior4(pl, begin, W, nxt);
+            load_interior4(pl, begin, W, span_left_index(begin, x0, y0, W), nxt);
             have_nxt = true;
         }
         for (uint32_t r0 = begin; r0 < end; r0 += 256) {
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_hist(const T *__restrict__ planes, uint
                 y1++;
             }
             have_nxt = r0 + 256 < end && is_interior(r0 + 256, x1, y1);
-            if (have_nxt) load_interior4(pl, r0 + 256, W, nxt);  // in flight while this trip is counted
+            if (have_nxt) load_interior4(pl, r0 + 256, W, span_left_index(r0 + 256, x1, y1, W), nxt);  // in flight while this trip is counted
             if (interior) {
                 // lane l takes pixels r0 + 4l .. + 3: two wide loads instead of twelve byte loads (counting
                 // does not care which lane sees which pixel)
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
     };
     uint32_t y0 = begin / W, x0 = begin - y0 * W;
     for (uint32_t row0 = begin; row0 < end; row0 += 256) {
-        const bool interior = y0 > 0 && x0 > 0 && x0 + 256 <= W && row0 + 256 <= end;
+        const bool interior = y0 > 0 && x0 + 256 <= W && row0 + 256 <= end;  // (a span from the first column included)
         // The events of the trip are compacted into a per-wave ring in LDS, raster order kept, and ranked /
         // stored 64 at a time: every ballot and every store then works on 64 events instead of the ~35 %
         // of a row's lanes that hold one.
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
             // sum of the lanes' event counts keeps the ring in raster order
             const uint32_t off0 = row0 - begin + 4 * lane;
             PixelClass pc[4];
-            classify_interior4(pl, row0, W, pc);
+            classify_interior4(pl, row0, W, span_left_index(row0, x0, y0, W), pc);
             uint32_t nev = 0;
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) nev += pc[j].cls != CLS_IN ? 1u : 0u;

@@ -1162,8 +1162,8 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ pla
 // so the output needs no zeroing.
 // ------------------------------------------------------------------------------------------
 
-constexpr uint32_t LOCAL_WORDS = 8;
-constexpr uint32_t FUSED_WIN_WORDS = PACK_TILE * 10 / 32;  // LDS bit window: 10 bits per pixel of a tile in one pass (more bits: more passes)
+constexpr uint32_t LOCAL_WORDS = 6;
+constexpr uint32_t FUSED_WIN_WORDS = PACK_TILE * 8 / 32;  // LDS bit window: 8 bits per pixel of a tile in one pass (more bits: more passes)
 // thread-private bit string, MSB-first, word w of thread t at buf[w * PACK_THREADS + t]
 struct LocalBits {
     uint32_t *buf;
@@ -1456,7 +1456,8 @@ extern "C" __attribute__((visibility("default"))) int felics_debug_pack_stamps(u
 }
 #endif
 
-// (u8 planes: six waves per SIMD -- 80 VGPRs, 25.6 KB of LDS per workgroup; i16 planes: four, 33.8 KB)
+// (u8 planes: k_pack_k runs seven waves per SIMD -- 72 VGPRs, 22.6 KB of LDS per workgroup: private bit buffers of six words
+// and a window of 8 bits per pixel are what makes seven fit, 4.15 -> 3.99 ms per step; i16 planes: five, 30.8 KB)
 template <typename T>
 __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_fused(const T *__restrict__ planes, const uint8_t *__restrict__ k_map,
                                                              FusedArgs fa, uint32_t tile_begin) {
@@ -1483,7 +1484,7 @@ struct KSources {
 };
 
 template <typename T, typename ET>
-__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_k(const T *__restrict__ planes, KSources ks, FusedArgs fa,
+__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 5))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_k(const T *__restrict__ planes, KSources ks, FusedArgs fa,
                                                                                                uint32_t sort_tile_begin, uint32_t pack_tile_end) {
     __shared__ TileLDS<T> tl;
     __shared__ FusedLDS fl;

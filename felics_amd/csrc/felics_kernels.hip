@@ -215,29 +215,38 @@ __global__ __launch_bounds__(OFF_SEGS *OFF_CTX) void k_tile_offsets(uint32_t *__
 
 // Exclusive scan of the chain lengths, each rounded up to a whole 64-event block, over all
 // (plane, ctx) -> chain_base; single block.  total_slots = end of the last chain.
-__global__ __launch_bounds__(1024) void k_chain_bases(const uint32_t *__restrict__ chain_len,
+// Thread t owns a contiguous run of chains: it sums them (all loads of the run in flight together), the run totals are
+// scanned across the block once, and the run is walked again writing the offsets -- two memory round trips and one
+// barrier phase.  256 threads, not 1024: a workgroup of sixteen waves waits for a CU with four free wave slots on every
+// SIMD at once, which a GPU full of pack and scatter workgroups does not offer for a long time (0.17 ms per launch).
+constexpr uint32_t CHAIN_BASES_THREADS = 256;
+__global__ __launch_bounds__(CHAIN_BASES_THREADS) void k_chain_bases(const uint32_t *__restrict__ chain_len,
                                                       uint32_t *__restrict__ chain_base, uint32_t n,
                                                       uint32_t *__restrict__ total_slots) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry;
+    __shared__ uint32_t wsum[CHAIN_BASES_THREADS / 64];
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < n ? ((chain_len[i] + 63u) & ~63u) : 0;
-        uint32_t inc = wave_incl_scan(v);
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
-        uint32_t c = carry;
-        if (i < n) chain_base[i] = c + woff + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = c + woff + inc;
-        __syncthreads();
+    const uint32_t per = (n + CHAIN_BASES_THREADS - 1u) / CHAIN_BASES_THREADS;
+    const uint32_t i0 = min(threadIdx.x * per, n), i1 = min(i0 + per, n);
+    uint32_t sum = 0;
+    uint32_t i = i0;
+    for (; i + 8 <= i1; i += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) v[u] = chain_len[i + u];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) sum += (v[u] + 63u) & ~63u;
     }
-    if (threadIdx.x == 0) *total_slots = carry;
+    for (; i < i1; i++) sum += (chain_len[i] + 63u) & ~63u;
+    const uint32_t inc = wave_incl_scan(sum);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (uint32_t w = 0; w < wave; w++) run += wsum[w];
+    for (i = i0; i < i1; i++) {
+        chain_base[i] = run;
+        run += (chain_len[i] + 63u) & ~63u;
+    }
+    if (threadIdx.x == CHAIN_BASES_THREADS - 1) *total_slots = run;  // (threads past the last chain carry the total along)
 }
 
 // Zero the padding events at the end of every chain's last block (value 0 adds nothing to a
@@ -1694,7 +1703,7 @@ void launch_offsets(hipStream_t s, uint32_t *counts, uint32_t *chain_len, uint32
     const uint32_t nchains = g.nplanes * g.nctx;
     FELICS_LAUNCH(k_tile_offsets, dim3(g.nctx / OFF_CTX, g.nplanes), dim3(OFF_SEGS * OFF_CTX), s, counts, chain_len,
                        g.sort_tiles, g.nctx);
-    FELICS_LAUNCH(k_chain_bases, dim3(1), dim3(1024), s, chain_len, chain_base, nchains, total_events);
+    FELICS_LAUNCH(k_chain_bases, dim3(1), dim3(CHAIN_BASES_THREADS), s, chain_len, chain_base, nchains, total_events);
 }
 
 template <typename T, typename ET>

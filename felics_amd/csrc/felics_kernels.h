@@ -164,7 +164,7 @@ void launch_pack_fused(hipStream_t s, const T *planes, const uint8_t *k_map, uin
                        uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last,
                        uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t t0, uint32_t t1, uint32_t epoch,
                        uint32_t *ticket /* one zeroed word per launch: tiles are handed out in order */);
-// The same pack with k computed inside it (k_pack_k): a workgroup takes one sort tile [st0, st1) = two pack tiles,
+// The same pack with k computed inside it (k_pack_k): a workgroup takes one sort tile of [st0, st1) (= one pack tile),
 // runs the assign step on the 64-event blocks its events lie in (block states from the spine) and keeps k in LDS.
 // No k_map, no k_assign launch.
 template <typename T, typename ET>

@@ -1497,11 +1497,6 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 5))) __global__ __launch
                                                                                                uint32_t sort_tile_begin, uint32_t pack_tile_end) {
     __shared__ TileLDS<T> tl;
     __shared__ FusedLDS fl;
-#ifdef FELICS_PACK_PAD_LDS  // experiment: fewer workgroups per CU, same code
-    __shared__ uint32_t pad_lds[FELICS_PACK_PAD_LDS / 4];
-    if (fa.epoch == 0xFFFFFFFFu) pad_lds[threadIdx.x] = fa.W;
-    if (fa.epoch == 0xFFFFFFFEu) fa.error[0] = pad_lds[threadIdx.x ^ 1];
-#endif
     static_assert(SORT_TILE == PACK_TILE, "one workgroup = one sort tile = one pack tile (one look-back per workgroup)");
     uint8_t *kq2 = tl.kq;
     uint32_t x, plane;

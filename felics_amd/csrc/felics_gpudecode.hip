@@ -8,8 +8,8 @@
 // one wave per stream, the estimator table (512 rows of six counters, 12 KiB) and the two image rows the
 // neighbour rule looks at in LDS, the stream pulled in 256 bytes at a time with coalesced loads, finished
 // rows stored coalesced.  A batch fills the chip from about a thousand streams up; a single stream runs at
-// the speed of one wave's instruction stream: ~1 250 cycles per pixel, whether that stream is vector code
-// (round 2's first form: 112 MPix/s for 64 streams) or, as now, scalar code (122 MPix/s) -- a lone wave
+// the speed of one wave's instruction stream: ~480 ns per pixel, whether that stream is vector code
+// (round 2's first form: 112 MPix/s for 64 streams) or, as now, scalar code (134 MPix/s) -- a lone wave
 // issues an instruction of either kind about every ten cycles and pays more for every taken branch.
 //
 // Valid streams decode to exactly the pixels the host decoder (felics_decode.cpp) produces.  Corrupt
@@ -45,7 +45,7 @@ struct ScalarBits {
     uint32_t cpos;         // next dword of `cur` to consume, 0..64
     uint64_t acc;          // unread bits, left-aligned
     uint32_t navail;       // valid bits in acc
-    int64_t bits_left;     // stream bits not handed out yet; negative = read past the end (DecompressionError::IoError)
+    uint64_t end_bit;      // bits from `al` to the end of the stream
 
     __device__ __forceinline__ uint32_t fetch(uint64_t first) const {
         const uint64_t i = first + lane_id();
@@ -61,7 +61,7 @@ struct ScalarBits {
         cpos = 0;
         acc = 0;
         navail = 0;
-        bits_left = (int64_t)(n * 8u);
+        end_bit = (skew + n) * 8u;
         refill();
         if (skew) {  // the first dword starts before the stream: drop those bytes
             acc <<= 8u * skew;
@@ -88,14 +88,16 @@ struct ScalarBits {
         const uint32_t v = n ? (uint32_t)(acc >> (64u - n)) : 0u;
         acc <<= n;
         navail -= n;
-        bits_left -= n;
         return v;
     }
     __device__ __forceinline__ uint32_t get(uint32_t n) {
         refill();
         return take(n);
     }
-    __device__ __forceinline__ bool failed() const { return bits_left < 0; }
+    // Bits past the end of the stream read as zeros, and whether any were handed out is worked out from the position when
+    // somebody asks (at the end of every row, and wherever decoding stops): DecompressionError::IoError.  Nothing loops on
+    // stream content without a bound: a run of ones ends at the first padding zero.
+    __device__ __forceinline__ bool failed() const { return (chunk0 + cpos) * 32u - navail > end_bit; }
     // ones before the first zero, the zero consumed (read_unary0)
     __device__ __forceinline__ uint64_t unary0() {
         uint64_t q = 0;
@@ -183,27 +185,20 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
             const uint32_t xl = x & 63u;
             if (xl == 0) {
                 if (y > 0) upv = (int)prev[x + lane];  // (rows are padded to whole blocks)
-                if (x == 0 && y >= 2) first_col2 = unii((int)cur[0]);
+                // second neighbour of the row's first pixel (misc.rs:14-23): two rows up -- what cur[0] still holds --
+                // or, in row 1, above-right
+                if (x == 0 && y > 0) first_col2 = y >= 2 ? unii((int)cur[0]) : (W > 1 ? __builtin_amdgcn_readlane(upv, 1) : 0);
             }
             int pv;
             if (i < 2) {
                 pv = i == 0 ? p0 : p1;
             } else {
                 const int above = __builtin_amdgcn_readlane(upv, (int)xl);
-                int v1, v2;  // misc.rs:6-24
-                if (x > 0 && y > 0) {
-                    v1 = left;
-                    v2 = above;
-                } else if (y == 0) {
-                    v1 = left;
-                    v2 = left2;
-                } else if (y >= 2) {  // first column: above and two rows up
-                    v1 = above;
-                    v2 = first_col2;
-                } else {  // pixel (0,1): above and above-right
-                    v1 = above;
-                    v2 = W > 1 ? __builtin_amdgcn_readlane(upv, 1) : 0;
-                }
+                // misc.rs:6-24 with selects: interior = left and above; first row = the two to the left; first column =
+                // above and first_col2
+                const bool row0 = y == 0, col0 = x == 0 && !row0;
+                const int v1 = col0 ? above : left;
+                const int v2 = col0 ? first_col2 : (row0 ? left2 : above);
                 const int hi = max(v1, v2), lo = min(v1, v2);
                 const uint32_t ctx = (uint32_t)(hi - lo);  // <= 510 because every stored sample is in range
                 br.refill();  // >= 33 bits: an in-range code has at most 11, the two flags of the other kind 2
@@ -212,9 +207,11 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
                     const uint32_t m = 31u - (uint32_t)__builtin_clz(n);
                     const uint32_t right_p = (2u << m) - n, left_p = n - (1u << m);
                     uint32_t r = br.take(m);
-                    if (r >= right_p) r = (r - right_p) * 2u + right_p + br.take(1);
+                    const uint32_t longer = r >= right_p ? 1u : 0u;  // the code has one more bit
+                    const uint32_t r2 = (r - right_p) * 2u + right_p + br.take(longer);
+                    r = longer ? r2 : r;
                     uint32_t rot = r + left_p;  // rotate_left: (r + left_p) mod n, r < n
-                    if (rot >= n) rot -= n;
+                    rot = rot >= n ? rot - n : rot;
                     pv = lo + (int)rot;
                 } else {
                     const bool above_flag = br.take(1) != 0;
@@ -228,10 +225,6 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
                     const uint32_t k = 7u - (key & 7u);
                     const uint64_t q = br.unary0();
                     const uint64_t e64 = (q << k) + br.get(k);
-                    if (br.failed()) {
-                        rc = FELICS_E_IO;
-                        break;
-                    }
                     if (e64 > 1024u) {  // no sample of an 8-bit plane is that far from its neighbours
                         rc = e64 > 0xFFFFFFFFull ? FELICS_E_VALUE_OVERFLOW : FELICS_E_INVALID_VALUE;
                         break;
@@ -249,10 +242,6 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
                     wrow[1] = (uint64_t)(S[2] >> hsh) | ((uint64_t)(S[3] >> hsh) << 32);
                     wrow[2] = (uint64_t)(S[4] >> hsh) | ((uint64_t)(S[5] >> hsh) << 32);
                     pv = above_flag ? hi + (int)e + 1 : lo - (int)e - 1;
-                }
-                if (br.failed()) {
-                    rc = FELICS_E_IO;
-                    break;
                 }
             }
             if (pv < lo_ok || pv > hi_ok) {  // try_into::<u8>() / the estimator's context bound would fail
@@ -274,6 +263,10 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
                 }
             }
             if (row_end) {
+                if (br.failed()) {
+                    rc = FELICS_E_IO;
+                    break;
+                }
                 __builtin_amdgcn_wave_barrier();
                 x = 0;
                 y++;
@@ -285,6 +278,7 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
             }
         }
     }
+    if (br.failed()) rc = FELICS_E_IO;  // (whatever else stopped the decoding: it was decoding padding)
     if (lane == 0) status[img] = rc;
 }
 

@@ -336,9 +336,11 @@ def main():
             if stage == "pack":
                 if args.depth16:
                     return "k_pack"
-                return "k_pack_fused" if os.environ.get("FELICS_ASSIGN") == "kernel" else "k_pack_k"
+                return {"kernel": "k_pack_fused", "inpack": "k_pack_k"}.get(os.environ.get("FELICS_ASSIGN", ""), "k_pack_g")
             if stage == "offsets":
                 return "k_tile_offsets"
+            if stage == "assign" and os.environ.get("FELICS_ASSIGN", "") not in ("kernel", "inpack") and not args.depth16:
+                return "k_assign_serial"
             return "k_" + stage
 
         if dom and stage_ms[dom] > 0:

@@ -3,6 +3,7 @@
 // failure.  The image is decoded on the host, encoded by libfelics on an MI355X, written to disk.
 #include <cerrno>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -11,6 +12,9 @@
 #include "image_io.h"
 
 int main(int argc, char **argv) {
+    // libfelics runs its stages on HIP streams of their own: ask the ROCm runtime for enough hardware queues before it
+    // starts (an application's choice, not the library's; a value already in the environment wins)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     CliArgs args = cli_parse(argc, argv, "cfelics", "Compresses an image file to a felics file", "The input file",
                              "The output felics file");
     imageio::Image img;

@@ -28,7 +28,13 @@ static_assert(ST_COUNT <= FELICS_MAX_STAGES, "felics.h promises at most FELICS_M
 
 constexpr int SLICES = 12;              // at most; a submission uses lane.nslices of them
 constexpr int EV_PAIRS = SLICES + 2;     // launches of one stage per sub-batch that can be timed
-constexpr int MAX_LANES = 2;            // submissions in flight (felics_submit_batch_device), each with streams and workspace of its own
+constexpr int MAX_LANES = 4;            // upper bound of the submissions in flight (felics_submit_batch_device), each with streams and workspace of its own
+constexpr int DEFAULT_LANES = 3;        // what a context uses unless FELICS_LANES says otherwise: with three, the spine chains (the one
+                                        // sequential part, ~3 ms per 4K frame) of two submissions run side by side while a third is in its front end
+int lanes_from_env() {
+    if (const char *e = getenv("FELICS_LANES")) return std::max(1, std::min(atoi(e), MAX_LANES));
+    return DEFAULT_LANES;
+}
 
 struct DevBuf {
     void *p = nullptr;
@@ -51,7 +57,7 @@ struct Lane {
     hipEvent_t sized = nullptr;       // stream sizes have landed in h_sizes
     uint64_t *h_sizes = nullptr;      // pinned: image_bytes[n] followed by image_off[n + 1]
     size_t h_sizes_cap = 0;
-    DevBuf planes, counts, chain_len, chain_base, chain_prog, scalars, sorted_e, pix_of, k_map, block_state, group_bits,
+    DevBuf planes, counts, chain_len, chain_base, chain_prog, scalars, sorted_e, pix_of, k_map, k_sorted, block_state, group_bits,
         tile_bits, tile_bitoff, plane_sums, image_bytes, image_off, partial, block_tag, status, edge_first, edge_last, pscratch;
     DevBuf wrecs[2], wtile_cnt, wmeta, whist, wdigtot, heads;  // 16-bit samples: event records (sort double buffer), tile counts, plane ranges, digit histograms, chain heads
     DevBuf s_ctl, s_table, s_status, s_stamps;                     // fused tile kernel: control block, estimator tables, look-back words
@@ -81,6 +87,7 @@ struct Lane {
 struct felics_ctx {
     int device = -1;
     int next_lane = 0;          // lane of the next felics_submit_batch_device
+    int nlanes = DEFAULT_LANES; // lanes in use (FELICS_LANES)
     // Slices per sub-batch.  A blocking call has the GPU to itself: more slices let assign / pack follow the
     // spine closely.  With two submissions in flight the other batch keeps the GPU busy, and every slice costs
     // a launch and a hand-over per stage: few slices are faster there (measured: 12 -> 5.3, 6 -> 5.1, 3 -> 4.8 ms).
@@ -90,8 +97,14 @@ struct felics_ctx {
                                 // (felics_stripe.hip) instead of the multi-kernel pipeline.  Measured slower so far,
                                 // hence opt-in; a hand-off of that kernel that gives up moves the context back for good
     uint32_t stripe_wgs = 256;  // workgroups of the persistent kernel: one per CU (its LDS fills a CU); FELICS_STRIPE_WGS
-    bool pack_k = true;         // the single-pass pack computes k itself, in LDS (k_pack_k): no k_assign launches, no k per pixel in HBM.
-                                // FELICS_ASSIGN=kernel selects the separate k_assign kernel + k_map again
+    // Where the k of the events comes from (FELICS_ASSIGN):
+    //   gather (default): k_assign_serial replays every 64-event block once, one lane per block, and leaves k in chain
+    //                     order (k_sorted); the single-pass pack gathers it through the runs of its tile (k_pack_g)
+    //   inpack:           the single-pass pack computes k itself, in LDS, with wave-wide prefix sums (k_pack_k, round 2)
+    //   kernel:           k_assign scatters k to a byte per pixel in HBM (k_map), which the pack stages (round 1)
+    enum AssignMode { ASSIGN_GATHER = 0, ASSIGN_INPACK = 1, ASSIGN_KERNEL = 2 };
+    int assign_mode = ASSIGN_GATHER;
+    bool pack_tickets = true;   // k_pack_g takes its tiles from a ticket counter (FELICS_TICKETS=0: from the workgroup index; needs the shared tail stream)
     bool two_pass = false;      // FELICS_TWO_PASS=1, or a look-back of the single-pass pack gave up once: lengths + pack kernels
     bool test_timeout = false;  // FELICS_TEST_TIMEOUT=1: every wait for the GPU reports a time-out (tests of the failed state)
     bool test_stripe_fail = false; // FELICS_TEST_STRIPE_FAIL=1: pretend the first fused-kernel submission gave up (tests)
@@ -271,6 +284,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     if ((rc = reserve(ctx, l.sorted_e, slots * sizeof(ET) + SORTED_PAD)) != 0) return rc;
     if ((rc = reserve(ctx, l.pix_of, slots * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.k_map, nsamples + STAGE_PAD)) != 0) return rc;
+    if ((rc = reserve(ctx, l.k_sorted, slots + STAGE_PAD)) != 0) return rc;
     if ((rc = reserve(ctx, l.block_state, (size_t)max_event_blocks(g) * 32)) != 0) return rc;
     if ((rc = reserve(ctx, l.partial, (size_t)SLICES * g.nplanes * g.nctx * 8)) != 0) return rc;
     if ((rc = reserve_zeroed(ctx, l.block_tag, (size_t)max_event_blocks(g) * 4)) != 0) return rc;
@@ -312,7 +326,9 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     // slots, so the lanes share the tail stream).  It puts planes 1, 2 of an RGB image into scratch slots of
     // their own and moves them behind plane 0 at the end.
     const bool fused = slot_stride != 0 && !ctx->two_pass;
-    const bool ink = fused && ctx->pack_k;  // k inside the pack kernel: the k stream has nothing to do
+    const bool ink = fused && ctx->assign_mode == felics_ctx::ASSIGN_INPACK;  // k inside the pack kernel: the k stream has nothing to do
+    const bool gather = fused && ctx->assign_mode == felics_ctx::ASSIGN_GATHER;  // k in chain order (k stream), gathered by the pack kernel
+    const bool rel = ink || gather;  // the pack kernel knows its tile: pix_of holds 16-bit offsets into the sort tile
     // Two-pass kernels: gray frames pack slice by slice; RGB packs after the last slice (the offset of planes
     // 1 and 2 in their stream needs the size of the planes before them).
     const bool pack_by_slice = slot_stride != 0 && g.planes_per_image == 1;
@@ -327,7 +343,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
 
     // ---- front stream
     if (ctx->poison) {  // FELICS_POISON: every intermediate buffer starts as garbage, as on a fresh context
-        DevBuf *bufs[] = {&l.counts, &l.chain_len, &l.chain_base, &l.sorted_e, &l.pix_of, &l.k_map, &l.block_state,
+        DevBuf *bufs[] = {&l.counts, &l.chain_len, &l.chain_base, &l.sorted_e, &l.pix_of, &l.k_map, &l.k_sorted, &l.block_state,
                           &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.edge_first, &l.edge_last, &l.pscratch};
         for (DevBuf *b : bufs)
             if (b->p) HIP_TRY(ctx, hipMemsetAsync(b->p, 0xA5, b->cap, f));
@@ -339,7 +355,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     {
         StageTimer t(ctx, l, ST_OFFSETS, f);
         launch_offsets(f, counts, chain_len, chain_base, (uint32_t *)l.scalars.p, g);
-        launch_zero_padding<ET>(f, (ET *)l.sorted_e.p, ink ? nullptr : (uint32_t *)l.pix_of.p, chain_base, chain_len, g);
+        launch_zero_padding<ET>(f, (ET *)l.sorted_e.p, rel ? nullptr : (uint32_t *)l.pix_of.p, chain_base, chain_len, g);
         HIP_TRY(ctx, hipMemsetAsync(chain_prog, 0, (size_t)g.nplanes * g.nctx * 32, f));
         HIP_TRY(ctx, hipMemsetAsync(l.partial.p, 0, (size_t)ns * g.nplanes * g.nctx * 8, f));
     }
@@ -351,7 +367,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     for (int q = 0; q < ns; q++) {
         if (bounds[q + 1] != bounds[q]) {
             StageTimer t(ctx, l, ST_SCATTER, f, true);
-            launch_scatter<T, ET>(f, d_planes, counts, chain_base, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, ink, g,
+            launch_scatter<T, ET>(f, d_planes, counts, chain_base, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, rel, g,
                                   bounds[q], bounds[q + 1]);
         }
         HIP_TRY(ctx, hipEventRecord(l.slice_done[q], f));
@@ -372,9 +388,14 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         HIP_TRY(ctx, hipStreamWaitEvent(ks, l.spine_done[q], 0));
         if (bounds[q + 1] != bounds[q] || q + 1 == ns) {
             StageTimer t(ctx, l, ST_ASSIGN, ks, true);
-            launch_assign<ET>(ks, (const ET *)l.sorted_e.p, (const uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
-                              (const uint32_t *)l.block_state.p, (const uint32_t *)l.scalars.p,
-                              (const uint32_t *)l.block_tag.p, (const uint32_t *)l.partial.p, epoch, (uint32_t)q + 1, g);
+            if (gather)
+                launch_assign_serial<ET>(ks, (const ET *)l.sorted_e.p, (uint8_t *)l.k_sorted.p, (const uint32_t *)l.block_state.p,
+                                         (const uint32_t *)l.scalars.p, (const uint32_t *)l.block_tag.p,
+                                         (const uint32_t *)l.partial.p, epoch, (uint32_t)q + 1, g);
+            else
+                launch_assign<ET>(ks, (const ET *)l.sorted_e.p, (const uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
+                                  (const uint32_t *)l.block_state.p, (const uint32_t *)l.scalars.p,
+                                  (const uint32_t *)l.block_tag.p, (const uint32_t *)l.partial.p, epoch, (uint32_t)q + 1, g);
         }
         HIP_TRY(ctx, hipEventRecord(l.assign_done[q], ks));
     }
@@ -386,7 +407,13 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         const bool last = q + 1 == ns;
         HIP_TRY(ctx, hipStreamWaitEvent(tl, ink ? l.spine_done[q] : l.assign_done[q], 0));
         if (bounds[q + 1] == bounds[q] && !last) continue;
-        if (ink) {
+        if (gather) {
+            StageTimer t(ctx, l, ST_PACK, tl, true);
+            launch_pack_g<T>(tl, d_planes, (const uint8_t *)l.k_sorted.p, (const uint32_t *)l.pix_of.p, counts, chain_base, chain_len,
+                             (uint64_t *)l.status.p, (uint64_t *)l.tile_bitoff.p, (uint32_t *)l.tile_bits.p, plane_carry,
+                             (uint32_t *)l.edge_first.p, (uint32_t *)l.edge_last.p, d_error, target, g, bounds[q], bounds[q + 1], epoch,
+                             ctx->pack_tickets ? d_tickets + q : nullptr);
+        } else if (ink) {
             {
                 StageTimer t(ctx, l, ST_PACK, tl, true);
                 launch_pack_k<T, ET>(tl, d_planes, (const ET *)l.sorted_e.p, (const uint32_t *)l.pix_of.p, (const uint32_t *)l.block_state.p,
@@ -903,15 +930,17 @@ int felics_ctx_create(int device, felics_ctx **out) {
     felics_ctx *ctx = new (std::nothrow) felics_ctx();
     if (!ctx) return FELICS_E_IO;
     ctx->device = device;
-    // Four streams want four hardware queues of their own; ROCm's default is 4 per process and the
-    // caller's stream takes one.  Only effective if the HIP runtime has not been initialised yet, and never
-    // overrides a value the process already has (overwrite = 0): a host application that manages its own
-    // queues sets GPU_MAX_HW_QUEUES itself (felics_amd/api.py and bench.py do so before loading anything).
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    // The lanes' streams want hardware queues of their own; ROCm's default is 4 per process and the caller's stream
+    // takes one.
+    // (A library does not touch the process environment: felics_amd/api.py, bench.py and the command lines ask for the
+    // hardware queues -- GPU_MAX_HW_QUEUES -- before the runtime starts.)
+    ctx->nlanes = lanes_from_env();
     ctx->poison = getenv("FELICS_POISON") != nullptr;
     ctx->two_pass = getenv("FELICS_TWO_PASS") != nullptr;
     ctx->test_lookback = getenv("FELICS_TEST_LOOKBACK_FAIL") != nullptr;
-    if (const char *e = getenv("FELICS_ASSIGN")) ctx->pack_k = strcmp(e, "kernel") != 0;
+    if (const char *e = getenv("FELICS_ASSIGN"))
+        ctx->assign_mode = strcmp(e, "kernel") == 0 ? felics_ctx::ASSIGN_KERNEL : strcmp(e, "inpack") == 0 ? felics_ctx::ASSIGN_INPACK : felics_ctx::ASSIGN_GATHER;
+    if (const char *e = getenv("FELICS_TICKETS")) ctx->pack_tickets = atoi(e) != 0 || getenv("FELICS_OWN_TAILS") != nullptr;
     ctx->test_stripe_fail = getenv("FELICS_TEST_STRIPE_FAIL") != nullptr;
     ctx->test_timeout = getenv("FELICS_TEST_TIMEOUT") != nullptr;
     if (const char *e = getenv("FELICS_PIPELINE")) ctx->stripe = strcmp(e, "stripe") == 0;
@@ -937,7 +966,8 @@ int felics_ctx_create(int device, felics_ctx **out) {
         if (strcmp(e, "frontfirst") == 0) prio_spine = prio_front = prio_high, prio_tail = prio_low;
         if (strcmp(e, "tailonly") == 0) prio_spine = prio_front = prio_low, prio_tail = prio_high;
     }
-    for (Lane &l : ctx->lanes) {
+    for (int li = 0; li < ctx->nlanes; li++) {
+        Lane &l = ctx->lanes[li];
         ok = ok && hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio_spine) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&l.front, hipStreamNonBlocking, prio_front) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&l.kstream, hipStreamNonBlocking, prio_tail) == hipSuccess;
@@ -982,7 +1012,7 @@ void felics_ctx_destroy(felics_ctx *ctx) {
     for (Lane &l : ctx->lanes)
         if (l.tail) (void)hipStreamSynchronize(l.tail);
     for (Lane &l : ctx->lanes) {
-        DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map,
+        DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map, &l.k_sorted,
                           &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.plane_sums, &l.image_bytes, &l.image_off,
                           &l.partial, &l.block_tag, &l.status, &l.edge_first, &l.edge_last, &l.pscratch, &l.wrecs[0], &l.wrecs[1], &l.wtile_cnt, &l.wmeta, &l.whist, &l.wdigtot, &l.heads,
                           &l.s_ctl, &l.s_table, &l.s_status, &l.s_stamps};
@@ -1071,12 +1101,12 @@ int felics_submit_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels, 
     }
     l.pending = true;
     *ticket = L;
-    ctx->next_lane = (L + 1) % MAX_LANES;
+    ctx->next_lane = (L + 1) % ctx->nlanes;
     return FELICS_OK;
 }
 
 int felics_wait_batch(felics_ctx *ctx, int ticket, uint64_t *offsets, uint64_t *lens) {
-    if (!ctx || ticket < 0 || ticket >= MAX_LANES || !offsets || !lens) return FELICS_E_INVALID_ARGUMENT;
+    if (!ctx || ticket < 0 || ticket >= ctx->nlanes || !offsets || !lens) return FELICS_E_INVALID_ARGUMENT;
     if (ctx->failed) return FELICS_E_HIP;
     Lane &l = ctx->lanes[ticket];
     if (!l.pending) return FELICS_E_INVALID_ARGUMENT;
@@ -1291,7 +1321,7 @@ int felics_get_stats(const felics_ctx *ctx, felics_stats *out) {
 
 int felics_stage_count(void) { return ST_COUNT; }
 
-int felics_lane_count(void) { return MAX_LANES; }
+int felics_lane_count(void) { return lanes_from_env(); }
 
 int felics_get_stage_launches(const felics_ctx *ctx, int *launches, int cap) {
     if (!ctx || !launches) return FELICS_E_INVALID_ARGUMENT;

@@ -110,25 +110,41 @@ __device__ __forceinline__ void load4(const int16_t *__restrict__ p, int (&v)[4]
 __device__ __forceinline__ uint32_t span_left_index(uint32_t first, uint32_t x, uint32_t y, uint32_t W) {
     return x > 0 ? first - 1 : (y >= 2 ? first - 2 * W : first - W + 1);
 }
+// (the samples stay packed as loaded -- one dword per four u8 samples, two per four i16 -- so that a ring of prefetched
+// trips costs three / five registers per entry; they are unpacked when the trip is classified)
+template <typename T>
 struct Interior4 {
-    int cur[4], up[4], left_lane0;
+    static constexpr uint32_t NW = sizeof(T);  // dwords per four samples
+    uint32_t cur[NW], up[NW];
+    int left_lane0;
 };
+
+__device__ __forceinline__ void unpack4(const uint32_t (&w)[1], int (&v)[4], uint8_t) {
+    v[0] = (int)(w[0] & 0xFFu); v[1] = (int)((w[0] >> 8) & 0xFFu); v[2] = (int)((w[0] >> 16) & 0xFFu); v[3] = (int)(w[0] >> 24);
+}
+__device__ __forceinline__ void unpack4(const uint32_t (&w)[2], int (&v)[4], int16_t) {
+    v[0] = (int)(int16_t)w[0]; v[1] = (int)w[0] >> 16; v[2] = (int)(int16_t)w[1]; v[3] = (int)w[1] >> 16;
+}
 
 template <typename T>
 __device__ __forceinline__ void load_interior4(const T *__restrict__ pl, uint32_t first, uint32_t W, uint32_t left_index,
-                                               Interior4 &v) {
+                                               Interior4<T> &v) {
     const uint32_t i = first + 4 * lane_id();
-    load4(pl + i, v.cur);
-    load4(pl + i - W, v.up);
+    __builtin_memcpy(v.cur, pl + i, 4 * sizeof(T));      // (possibly unaligned) 4- or 8-byte loads
+    __builtin_memcpy(v.up, pl + i - W, 4 * sizeof(T));
     v.left_lane0 = (int)pl[left_index];  // span_left_index(); same address in every lane: one scalar-like access
 }
 
-__device__ __forceinline__ void classify_loaded4(const Interior4 &v, PixelClass (&pc)[4]) {
-    int left0 = __builtin_amdgcn_update_dpp(0, v.cur[3], 0x138, 0xF, 0xF, false);  // wave_shr:1
+template <typename T>
+__device__ __forceinline__ void classify_loaded4(const Interior4<T> &v, PixelClass (&pc)[4]) {
+    int cur[4], up[4];
+    unpack4(v.cur, cur, T());
+    unpack4(v.up, up, T());
+    int left0 = __builtin_amdgcn_update_dpp(0, cur[3], 0x138, 0xF, 0xF, false);  // wave_shr:1
     if (lane_id() == 0) left0 = v.left_lane0;
-    pc[0] = classify_values(v.cur[0], left0, v.up[0]);
+    pc[0] = classify_values(cur[0], left0, up[0]);
 #pragma unroll
-    for (int j = 1; j < 4; j++) pc[j] = classify_values(v.cur[j], v.cur[j - 1], v.up[j]);
+    for (int j = 1; j < 4; j++) pc[j] = classify_values(cur[j], cur[j - 1], up[j]);
 }
 
 template <typename T>

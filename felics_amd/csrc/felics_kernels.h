@@ -173,6 +173,18 @@ void launch_pack_k(hipStream_t s, const T *planes, const ET *sorted_e, const uin
                    uint64_t *tile_bitoff, uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last,
                    uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t st0, uint32_t st1, uint32_t epoch,
                    uint32_t *ticket);
+// The same pack with k gathered from chain order (k_pack_g) and the kernel that puts it there (k_assign_serial: one lane
+// replays one 64-event block, k_sorted[slot] = k of the event in that slot; launched per slice behind the spine like
+// launch_assign).  k_sorted needs max_event_slots() + STAGE_PAD bytes.
+template <typename ET>
+void launch_assign_serial(hipStream_t s, const ET *sorted_e, uint8_t *k_sorted, const uint32_t *block_state,
+                          const uint32_t *total_slots, const uint32_t *block_tag, const uint32_t *partial, uint32_t epoch,
+                          uint32_t slice, const Geometry &g);
+template <typename T>
+void launch_pack_g(hipStream_t s, const T *planes, const uint8_t *k_sorted, const uint32_t *pix_of, const uint32_t *tile_off,
+                   const uint32_t *chain_base, const uint32_t *chain_len, uint64_t *status, uint64_t *tile_bitoff,
+                   uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last, uint32_t *error,
+                   const PackTarget &to, const Geometry &g, uint32_t st0, uint32_t st1, uint32_t epoch, uint32_t *ticket);
 void launch_join_edges(hipStream_t s, const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint32_t *edge_first,
                        const uint32_t *edge_last, const PackTarget &to, const Geometry &g);
 void launch_concat_planes(hipStream_t s, const uint64_t *plane_base, const uint64_t *plane_carry, const PackTarget &to,

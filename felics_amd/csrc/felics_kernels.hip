@@ -91,73 +91,86 @@ __global__ __launch_bounds__(256) void k_rgb8_to_planes(const uint8_t *__restric
 template <typename T>
 __global__ __launch_bounds__(256) void k_hist(const T *__restrict__ planes, uint32_t *__restrict__ counts,
                                               uint32_t W, uint32_t npix, uint32_t ntiles) {
-    __shared__ uint32_t hist[4][nctx_of<T>()];
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    // COPIES histograms per wave, lane l counts in copy l % COPIES: a smooth frame has ten contexts that matter, so the 64
+    // lanes of an LDS add hit a handful of addresses -- with one copy four fifths of the kernel's LDS cycles were conflicts
+    // (SQ_LDS_BANK_CONFLICT 84 M of SQ_LDS_IDX_ACTIVE 103 M cycles per step).
+    constexpr uint32_t NC = nctx_of<T>();
+    constexpr uint32_t COPIES = 4096 / NC / 4;  // 16 KB of LDS per workgroup either way: 4 (u8) or 2 (i16)
+    __shared__ uint32_t hist[4][COPIES][NC];
+    // (wave-uniform, and said so: the tile, its bounds and the trip bookkeeping then live in scalar registers instead of
+    // vector registers under exec masks -- without it three quarters of this kernel's instructions were mask handling)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
     const uint32_t tile = blockIdx.x * 4 + wave;
     const uint32_t plane = blockIdx.y;
-    constexpr uint32_t NC = nctx_of<T>();
-    for (uint32_t c = lane; c < NC; c += 64) hist[wave][c] = 0;
+    for (uint32_t c = lane; c < NC * COPIES; c += 64) hist[wave][0][c] = 0;
+    uint32_t *my_hist = hist[wave][lane % COPIES];
     __builtin_amdgcn_wave_barrier();
     if (tile < ntiles) {
         const T *pl = planes + (uint64_t)plane * npix;
         const uint32_t begin = tile * SORT_TILE;
         const uint32_t end = min(begin + SORT_TILE, npix);
-        // Four rows per trip: the twelve loads of a trip are in flight together.  (x0, y0) is the
-        // trip's first pixel, tracked in scalar registers; a trip whose 256 pixels lie inside one image
-        // row with x > 0, y > 0 -- nearly all of them -- takes the neighbour rule's interior case
-        // without any per-pixel case analysis.
-        uint32_t y0 = begin / W, x0 = begin - y0 * W;
+        // 256 pixels per trip, four per lane.  (x0, y0) is the trip's first pixel, tracked in scalar registers; a trip whose
+        // 256 pixels lie inside one image row with y > 0 -- nearly all of them -- takes the neighbour rule's interior case
+        // without any per-pixel case analysis, from two wide loads per lane.  The loads of the next HIST_AHEAD trips are in
+        // flight while a trip is counted: a wave walks its tile in 16 trips, and with one trip in flight the kernel was a
+        // chain of 16 memory round trips per tile.
+        constexpr uint32_t AHEAD = 4;
         auto is_interior = [&](uint32_t r, uint32_t x, uint32_t y) { return y > 0 && x + 256 <= W && r + 256 <= end; };
-        Interior4 nxt;
-        bool have_nxt = false;  // the next trip's loads were issued during the trip before
-        if (begin < end && is_interior(begin, x0, y0)) {
-            load_interior4(pl, begin, W, span_left_index(begin, x0, y0, W), nxt);
-            have_nxt = true;
-        }
-        for (uint32_t r0 = begin; r0 < end; r0 += 256) {
-            PixelClass pc[4];
-            bool ev[4];
-            const bool interior = have_nxt;
-            const Interior4 now = nxt;
-            // where the next trip starts
-            uint32_t x1 = x0 + 256, y1 = y0;
-            while (x1 >= W) {
-                x1 -= W;
-                y1++;
+        Interior4<T> ring[AHEAD];
+        bool have[AHEAD];
+        uint32_t ri = begin, yi = begin / W, xi = begin - yi * W;  // the next trip to issue
+        auto issue = [&](Interior4<T> &slot, bool &h) {
+            h = ri < end && is_interior(ri, xi, yi);
+            if (h) load_interior4(pl, ri, W, span_left_index(ri, xi, yi, W), slot);
+            ri += 256;
+            xi += 256;
+            if (xi >= W) {  // (once per image row: scalar division)
+                const uint32_t q = xi / W;
+                yi += q;
+                xi -= q * W;
             }
-            have_nxt = r0 + 256 < end && is_interior(r0 + 256, x1, y1);
-            if (have_nxt) load_interior4(pl, r0 + 256, W, span_left_index(r0 + 256, x1, y1, W), nxt);  // in flight while this trip is counted
-            if (interior) {
-                // lane l takes pixels r0 + 4l .. + 3: two wide loads instead of twelve byte loads (counting
-                // does not care which lane sees which pixel)
-                classify_loaded4(now, pc);
+        };
 #pragma unroll
-                for (uint32_t u = 0; u < 4; u++) ev[u] = pc[u].cls != CLS_IN;
-            } else {
-                Coord xy;
-                xy.x = x0;
-                xy.y = y0;
-                xy.advance(lane, W);
+        for (uint32_t d = 0; d < AHEAD; d++) issue(ring[d], have[d]);
+        for (uint32_t r0 = begin; r0 < end;) {
 #pragma unroll
-                for (uint32_t u = 0; u < 4; u++) {
-                    const uint32_t i = r0 + u * 64 + lane;
-                    ev[u] = false;
-                    if (i < end && i >= 2) {
-                        pc[u] = classify(pl, i, xy.x, xy.y, W);
-                        ev[u] = pc[u].cls != CLS_IN;
+            for (uint32_t d = 0; d < AHEAD; d++) {
+                if (r0 < end) {
+                    const bool interior = have[d];
+                    const Interior4<T> now = ring[d];
+                    issue(ring[d], have[d]);  // in flight while this trip (and the next AHEAD - 1) are counted
+                    if (interior) {
+                        // lane l takes pixels r0 + 4l .. + 3 (counting does not care which lane sees which pixel)
+                        PixelClass pc[4];
+                        classify_loaded4(now, pc);
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; u++)
+                            if (pc[u].cls != CLS_IN) atomicAdd(&my_hist[pc[u].ctx], 1u);
+                    } else {  // (a trip that crosses a row end, or lies in the first row: the general neighbour rule)
+                        Coord xy;
+                        xy.set(r0 + lane, W);
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; u++) {
+                            const uint32_t i = r0 + u * 64 + lane;
+                            if (i < end && i >= 2) {
+                                const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
+                                if (pc.cls != CLS_IN) atomicAdd(&my_hist[pc.ctx], 1u);
+                            }
+                            xy.advance(64, W);
+                        }
                     }
-                    xy.advance(64, W);
+                    r0 += 256;
                 }
             }
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++)
-                if (ev[u]) atomicAdd(&hist[wave][pc[u].ctx], 1u);
-            x0 = x1;
-            y0 = y1;
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t *dst = counts + ((uint64_t)plane * ntiles + tile) * NC;
-        for (uint32_t c = lane; c < NC; c += 64) dst[c] = hist[wave][c];
+        for (uint32_t c = lane; c < NC; c += 64) {
+            uint32_t n = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < COPIES; q++) n += hist[wave][q][c];
+            dst[c] = n;
+        }
     }
 }
 
@@ -280,10 +293,11 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
                                                  uint32_t W, uint32_t npix, uint32_t ntiles, uint32_t tile_begin,
                                                  uint32_t tile_end) {
     constexpr uint32_t RING = 512;  // a trip adds at most 256 events to fewer than 64 left over
+    static_assert(RING >= 256 + 64 && (RING & (RING - 1)) == 0, "the ring holds a trip's events behind a partial batch, and is indexed with a mask");
     static_assert(SORT_TILE <= (1u << 13), "ring records keep the pixel's offset in its tile in 13 bits");
     __shared__ uint32_t runs[4][nctx_of<T>()];
     __shared__ uint32_t rings[4][RING];
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();  // (uniform: see k_hist)
     const uint32_t tile = tile_begin + blockIdx.x * 4 + wave;
     const uint32_t plane = blockIdx.y;
     if (tile >= tile_end) return;
@@ -345,69 +359,88 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
                 pix_of[dest] = plane_first + begin + off;
         }
     };
-    uint32_t y0 = begin / W, x0 = begin - y0 * W;
-    for (uint32_t row0 = begin; row0 < end; row0 += 256) {
-        const bool interior = y0 > 0 && x0 + 256 <= W && row0 + 256 <= end;  // (a span from the first column included)
-        // The events of the trip are compacted into a per-wave ring in LDS, raster order kept, and ranked /
-        // stored 64 at a time: every ballot and every store then works on 64 events instead of the ~35 %
-        // of a row's lanes that hold one.
-        if (interior) {
-            // lane l takes pixels row0 + 4l .. + 3 (two wide loads instead of twelve byte loads); a prefix
-            // sum of the lanes' event counts keeps the ring in raster order
-            const uint32_t off0 = row0 - begin + 4 * lane;
-            PixelClass pc[4];
-            classify_interior4(pl, row0, W, span_left_index(row0, x0, y0, W), pc);
-            uint32_t nev = 0;
+    // The loads of the next AHEAD trips are in flight while a trip is compacted, ranked and stored (see k_hist).
+    constexpr uint32_t AHEAD = 3;
+    auto is_interior = [&](uint32_t r, uint32_t x, uint32_t y) { return y > 0 && x + 256 <= W && r + 256 <= end; };  // (a span from the first column included)
+    Interior4<T> pre[AHEAD];
+    bool have[AHEAD];
+    uint32_t ri = begin, yi = begin / W, xi = begin - yi * W;  // the next trip to issue
+    auto issue = [&](Interior4<T> &slot, bool &h) {
+        h = ri < end && is_interior(ri, xi, yi);
+        if (h) load_interior4(pl, ri, W, span_left_index(ri, xi, yi, W), slot);
+        ri += 256;
+        xi += 256;
+        if (xi >= W) {  // (once per image row: scalar division)
+            const uint32_t q = xi / W;
+            yi += q;
+            xi -= q * W;
+        }
+    };
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++) nev += pc[j].cls != CLS_IN ? 1u : 0u;
-            const uint32_t incl = wave_incl_scan(nev);
-            uint32_t pos = qtail + incl - nev;
+    for (uint32_t d = 0; d < AHEAD; d++) issue(pre[d], have[d]);
+    for (uint32_t row0 = begin; row0 < end;) {
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                if (pc[j].cls != CLS_IN) {
-                    ring[pos & (RING - 1u)] = (pc[j].ctx << 22) | (pc[j].val << 13) | (off0 + j);
-                    pos++;
+        for (uint32_t d = 0; d < AHEAD; d++) {
+            if (row0 < end) {
+                const bool interior = have[d];
+                const Interior4<T> now = pre[d];
+                issue(pre[d], have[d]);
+                // The events of the trip are compacted into a per-wave ring in LDS, raster order kept, and ranked /
+                // stored 64 at a time: every ballot and every store then works on 64 events instead of the ~35 %
+                // of a row's lanes that hold one.
+                if (interior) {
+                    // lane l takes pixels row0 + 4l .. + 3 (two wide loads instead of twelve byte loads); a prefix
+                    // sum of the lanes' event counts keeps the ring in raster order
+                    const uint32_t off0 = row0 - begin + 4 * lane;
+                    PixelClass pc[4];
+                    classify_loaded4(now, pc);
+                    uint32_t nev = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) nev += pc[j].cls != CLS_IN ? 1u : 0u;
+                    const uint32_t incl = wave_incl_scan(nev);
+                    uint32_t pos = qtail + incl - nev;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) {
+                        if (pc[j].cls != CLS_IN) {
+                            ring[pos & (RING - 1u)] = (pc[j].ctx << 22) | (pc[j].val << 13) | (off0 + j);
+                            pos++;
+                        }
+                    }
+                    qtail += readlane(incl, 63);
+                } else {
+                    bool evs[4];
+                    uint32_t cs[4], es[4];
+                    Coord xy;
+                    xy.set(row0 + lane, W);
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {
+                        const uint32_t i = row0 + u * 64 + lane;
+                        evs[u] = false;
+                        cs[u] = 0;
+                        es[u] = 0;
+                        if (i < end && i >= 2) {
+                            const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
+                            evs[u] = pc.cls != CLS_IN;
+                            cs[u] = pc.ctx;
+                            es[u] = pc.val;
+                        }
+                        xy.advance(64, W);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {  // row by row, lane by lane
+                        const uint64_t m = __ballot(evs[u]);
+                        if (m == 0) continue;
+                        if (evs[u]) ring[(qtail + mbcnt(m)) & (RING - 1u)] = (cs[u] << 22) | (es[u] << 13) | (row0 - begin + u * 64 + lane);
+                        qtail += (uint32_t)__popcll(m);
+                    }
+                }
+                row0 += 256;
+                __builtin_amdgcn_wave_barrier();
+                while (qtail - qhead >= 64u) {
+                    drain(64u);
+                    qhead += 64u;
                 }
             }
-            qtail += readlane(incl, 63);
-        } else {
-            bool evs[4];
-            uint32_t cs[4], es[4];
-            Coord xy;
-            xy.x = x0;
-            xy.y = y0;
-            xy.advance(lane, W);
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t i = row0 + u * 64 + lane;
-                evs[u] = false;
-                cs[u] = 0;
-                es[u] = 0;
-                if (i < end && i >= 2) {
-                    const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
-                    evs[u] = pc.cls != CLS_IN;
-                    cs[u] = pc.ctx;
-                    es[u] = pc.val;
-                }
-                xy.advance(64, W);
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {  // row by row, lane by lane
-                const uint64_t m = __ballot(evs[u]);
-                if (m == 0) continue;
-                if (evs[u]) ring[(qtail + mbcnt(m)) & (RING - 1u)] = (cs[u] << 22) | (es[u] << 13) | (row0 - begin + u * 64 + lane);
-                qtail += (uint32_t)__popcll(m);
-            }
-        }
-        x0 += 256;
-        while (x0 >= W) {
-            x0 -= W;
-            y0++;
-        }
-        __builtin_amdgcn_wave_barrier();
-        while (qtail - qhead >= 64u) {
-            drain(64u);
-            qhead += 64u;
         }
     }
     if (qtail != qhead) drain(qtail - qhead);
@@ -729,6 +762,128 @@ __global__ __launch_bounds__(256) void k_assign(const ET *__restrict__ sorted_e,
             const uint32_t gb = readlane(entry.x, b), valid = readlane(entry.y, b);
             const BlockIn in = load_block<ET>(st, sorted_e, pix_of, gb);
             assign_block(in, valid, k_map);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k of every event, in CHAIN order (k_assign_serial): one LANE per 64-event block.
+//
+// A lane loads its block's start state (k_spine) and its 64 events and replays the estimator event by event
+// (parameter_selection.rs:49-85): k = argmin of the six counters, ties to the largest k (`<=` at :79), taken BEFORE the
+// update (compression.rs:127,139); update; halve when the minimum exceeds 1024.  No cross-lane operation: 64 lanes = 64
+// independent blocks, ~30 instructions per event instead of the ~290 lane-instructions per event of the wave-wide
+// prefix-sum form (assign_block), and every block is computed exactly once.  k leaves as one byte per event slot,
+// 64 consecutive bytes per lane (k_sorted[slot]): the pack stage gathers it through the runs of its tile
+// (k_pack_g), so nothing is scattered to pixel order in HBM.
+//
+// The six counters are kept as KEYS: key_k = S_k << 3 | (7 - k).  The smallest key names the smallest counter and,
+// among equal counters, the largest k; min(S) > 1024 <=> min key >= 1025 << 3.
+// The kernel runs once per slice behind that slice's spine launch and serves what it published, like k_assign: the
+// blocks tagged with this launch's stamp (thread = block) and, per chain, the block whose events are in place but
+// which is not full yet (thread = chain, behind the block threads).
+// ------------------------------------------------------------------------------------------
+
+struct EstKeys {
+    uint32_t k0, k1, k2, k3, k4, k5, m;  // m = the smallest key (kept up to date by set / step)
+    __device__ __forceinline__ void set(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t s4, uint32_t s5) {
+        k0 = (s0 << 3) | 7u; k1 = (s1 << 3) | 6u; k2 = (s2 << 3) | 5u;
+        k3 = (s3 << 3) | 4u; k4 = (s4 << 3) | 3u; k5 = (s5 << 3) | 2u;
+        m = min_key();
+    }
+    __device__ __forceinline__ uint32_t min_key() const { return min(min(min(k0, k1), k2), min(min(k3, k4), k5)); }
+    // one event: returns 7 - k (k = get_k before the update), then update + halving
+    __device__ __forceinline__ uint32_t step(uint32_t e) {
+        const uint32_t r = m & 7u;
+        const uint32_t e8 = e << 3;
+        k0 += e8 + 8u;
+        k1 += ((e8 >> 1) & ~7u) + 16u;
+        k2 += ((e8 >> 2) & ~7u) + 24u;
+        k3 += ((e8 >> 3) & ~7u) + 32u;
+        k4 += ((e8 >> 4) & ~7u) + 40u;
+        k5 += ((e8 >> 5) & ~7u) + 48u;
+        m = min_key();
+        if (m >= (1025u << 3)) {  // x /= 2 on every counter (parameter_selection.rs:62)
+            k0 = ((k0 >> 1) & ~7u) | 7u; k1 = ((k1 >> 1) & ~7u) | 6u; k2 = ((k2 >> 1) & ~7u) | 5u;
+            k3 = ((k3 >> 1) & ~7u) | 4u; k4 = ((k4 >> 1) & ~7u) | 3u; k5 = ((k5 >> 1) & ~7u) | 2u;
+            m = min_key();
+        }
+        return r;
+    }
+};
+
+// replays block gb from its start state and stores the k of its 64 events (one 16-byte store per 16 events)
+template <typename ET>
+__device__ __forceinline__ void replay_block(const ET *__restrict__ sorted_e, const uint32_t *__restrict__ block_state,
+                                             uint8_t *__restrict__ k_sorted, uint32_t gb) {
+    const uint4 sa = reinterpret_cast<const uint4 *>(block_state)[(uint64_t)gb * 2];
+    const uint4 sb = reinterpret_cast<const uint4 *>(block_state)[(uint64_t)gb * 2 + 1];
+    constexpr uint32_t EPW = 4 / sizeof(ET);       // events per dword
+    constexpr uint32_t NW = 64 / EPW;              // dwords per block
+    const uint4 *src = reinterpret_cast<const uint4 *>(sorted_e + (uint64_t)gb * 64);
+    uint32_t w[NW];
+#pragma unroll
+    for (uint32_t q = 0; q < NW / 4; q++) {
+        const uint4 v = src[q];
+        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+    EstKeys est;
+    est.set(sa.x, sa.y, sa.z, sa.w, sb.x, sb.y);
+    uint4 *dst = reinterpret_cast<uint4 *>(k_sorted + (uint64_t)gb * 64);
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) {  // sixteen events -> four k dwords -> one store
+        uint32_t kw[4];
+#pragma unroll
+        for (uint32_t d = 0; d < 4; d++) {
+            uint32_t kk = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 4; b++) {
+                const uint32_t i = c * 16 + d * 4 + b;  // event index in the block
+                const uint32_t word = w[i / EPW], sh = (i % EPW) * 8u * sizeof(ET);
+                const uint32_t e = sizeof(ET) == 1 ? (word >> sh) & 0xFFu : (word >> sh) & 0xFFFFu;
+                kk |= est.step(e) << (8u * b);
+            }
+            kw[d] = kk ^ 0x07070707u;  // 7 - (7 - k) in every byte
+        }
+        dst[c] = make_uint4(kw[0], kw[1], kw[2], kw[3]);
+    }
+}
+
+// Persistent: a fixed grid strides over the blocks of the pass (their number is only known on the device); a wave looks at
+// 64 consecutive tags at a time -- the blocks a spine launch resolved are long runs of consecutive blocks of the long
+// chains, so a wave's 64 lanes are nearly always all busy or all idle.
+template <typename ET>
+__global__ __launch_bounds__(256) void k_assign_serial(const ET *__restrict__ sorted_e, const uint32_t *__restrict__ block_state,
+                                                       uint8_t *__restrict__ k_sorted, const uint32_t *__restrict__ total_slots,
+                                                       const uint32_t *__restrict__ block_tag, const uint2 *__restrict__ partial,
+                                                       uint32_t nchains, uint32_t stamp) {
+    const uint32_t nblocks = *total_slots >> 6;
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t b0 = blockIdx.x * 256; b0 < nblocks; b0 += stride) {
+        const uint32_t gb = b0 + threadIdx.x;
+        if (gb < nblocks && block_tag[gb] == stamp) replay_block<ET>(sorted_e, block_state, k_sorted, gb);
+    }
+    // per chain: the block whose events are in place but which is not full yet
+    for (uint32_t chain = blockIdx.x * 256 + threadIdx.x; chain < nchains; chain += stride) {
+        const uint2 entry = partial[chain];  // {block, events in place}; y == 0: no such block after this slice
+        if (entry.y == 0) continue;
+        // Replay what is there.  Stores go out as whole dwords, so up to three slots behind the last event in place receive
+        // a k computed from whatever those slots hold; they belong to later tiles, whose pack launches only run after a
+        // later launch of this kernel has replayed the whole block.  (A separate code path with a run-time bound: the main
+        // path above is fully unrolled.)
+        const uint32_t nvalid = (entry.y + 3u) & ~3u;
+        const uint32_t gb = entry.x;
+        const uint4 sa = reinterpret_cast<const uint4 *>(block_state)[(uint64_t)gb * 2];
+        const uint4 sb = reinterpret_cast<const uint4 *>(block_state)[(uint64_t)gb * 2 + 1];
+        EstKeys est;
+        est.set(sa.x, sa.y, sa.z, sa.w, sb.x, sb.y);
+        const ET *src = sorted_e + (uint64_t)gb * 64;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(k_sorted + (uint64_t)gb * 64);
+        for (uint32_t i = 0; i < nvalid; i += 4) {
+            uint32_t kk = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 4; b++) kk |= est.step((uint32_t)src[i + b]) << (8u * b);
+            dst[i >> 2] = kk ^ 0x07070707u;
         }
     }
 }
@@ -1249,25 +1404,144 @@ struct FusedLDS {
 #ifdef FELICS_PACK_STAMPS
     unsigned long long t_last, t_acc[12];
 #endif
-    uint32_t win[FUSED_WIN_WORDS];
+    // lbuf is followed by win: "row LOCAL_WORDS" of lbuf is the first KB of win, which nothing uses while the bit strings
+    // are built -- the row a string's words beyond LOCAL_WORDS are dumped in without a branch (fast_group)
     uint32_t lbuf[LOCAL_WORDS * PACK_THREADS];
+    uint32_t win[FUSED_WIN_WORDS];
     uint32_t wsum[PACK_THREADS / 64];
     uint64_t tile_lo_sh;
     uint32_t ticket_sh;
 };
 
+// Whether this thread's 16-pixel group takes the branch-free path (fast_group), and what that path needs from outside the
+// tile's LDS image: the position of the group's first-column pixel (PACK_PER_THREAD: none) and that pixel's second neighbour
+// (two rows up, or above-right in row 1: misc.rs:14-23).  Computed early by the kernels, so that the one global load is
+// long back when the group is coded.
+struct GroupGeom {
+    bool fast;
+    uint32_t j0;
+    int special;
+};
+template <typename T>
+__device__ __forceinline__ GroupGeom group_geometry(const T *__restrict__ pl, uint32_t tile, uint32_t W, uint32_t npix) {
+    GroupGeom gg{false, PACK_PER_THREAD, 0};
+    const uint32_t first = tile * PACK_TILE + threadIdx.x * PACK_PER_THREAD;
+    const uint32_t end = min((tile + 1) * PACK_TILE, npix);
+    // the whole group below the first image row and inside the plane, at most one first-column pixel in it
+    if (W >= PACK_PER_THREAD && first + PACK_PER_THREAD <= end && first >= W) {
+        gg.fast = true;
+        Coord xy;
+        xy.set(first, W);
+        if (xy.x == 0) gg.j0 = 0;
+        else if (xy.x + PACK_PER_THREAD > W) gg.j0 = W - xy.x;
+        if (gg.j0 < PACK_PER_THREAD) {
+            const uint32_t i0 = first + gg.j0;
+            gg.special = (int)pl[i0 >= 2 * W ? i0 - 2 * W : i0 - W + 1];
+        }
+    }
+    return gg;
+}
+
+// The bit string of a thread's 16 pixels WITHOUT a branch (the common case): every pixel below the first image row, the
+// group inside the plane.  Same result as walk_group + put_pixel + LocalBits, which stay as the general path (first row,
+// the plane's first two samples and its ragged end, codes longer than 32 bits, images narrower than 16 pixels).
+//   * neighbours: left and above (misc.rs:6-24, interior case).  A first-column pixel takes above and two rows up (above-right
+//     in row 1) instead; the pair is unordered (H = max, L = min), so that rule only replaces the LEFT sample of that one
+//     pixel by `special`, which the caller fetched: the left samples are a byte-shifted copy of the group, patched once.
+//   * both codes of a pixel are built (compression.rs:29-45 + phase_in_coding.rs:59-84 / rice_coding.rs:26-38), one is kept.
+//   * the string is appended to a 64-bit window whose upper word is stored every time (row `word`, clamped to the dump row
+//     behind the thread's LOCAL_WORDS words); it is stored for good the time it is complete.
+// Returns the string's length in bits, or ~0 if a code was longer than 32 bits (the caller then redoes the group).
+template <typename T>
+__device__ __forceinline__ uint32_t fast_group(const TileLDS<T> &t, const uint8_t *kq, uint32_t *lrow, uint32_t j0, int special) {
+    constexpr uint32_t NW = PACK_PER_THREAD * sizeof(T) / 4;  // dwords holding the group's samples
+    constexpr uint32_t PER = 4 / sizeof(T);                    // samples per dword
+    const uint32_t off = threadIdx.x * PACK_PER_THREAD;
+    uint32_t cw[NW], uw[NW], lw[NW], kw[4];
+#pragma unroll
+    for (uint32_t q = 0; q < NW / 4; q++) {
+        const uint4 a = reinterpret_cast<const uint4 *>(t.cur + STAGE_LEAD + off)[q];
+        const uint4 b = reinterpret_cast<const uint4 *>(t.up + off)[q];
+        cw[4 * q] = a.x; cw[4 * q + 1] = a.y; cw[4 * q + 2] = a.z; cw[4 * q + 3] = a.w;
+        uw[4 * q] = b.x; uw[4 * q + 1] = b.y; uw[4 * q + 2] = b.z; uw[4 * q + 3] = b.w;
+    }
+    {
+        const uint4 c = *reinterpret_cast<const uint4 *>(kq + off);
+        kw[0] = c.x; kw[1] = c.y; kw[2] = c.z; kw[3] = c.w;
+    }
+    // left samples: the group shifted up by one sample, the sample in front of the group shifted in
+    const uint32_t before = reinterpret_cast<const uint32_t *>(t.cur + STAGE_LEAD + off)[-1];
+#pragma unroll
+    for (uint32_t q = 0; q < NW; q++) lw[q] = __builtin_amdgcn_alignbyte(cw[q], q ? cw[q - 1] : before, 4 - sizeof(T));
+    if (j0 < PACK_PER_THREAD) {
+        const uint32_t qd = j0 / PER, sh = (j0 % PER) * 8u * sizeof(T);
+        constexpr uint32_t FIELD = sizeof(T) == 1 ? 0xFFu : 0xFFFFu;
+        const uint32_t mask = FIELD << sh, val = ((uint32_t)special & FIELD) << sh;
+#pragma unroll
+        for (uint32_t q = 0; q < NW; q++)
+            if (q == qd) lw[q] = (lw[q] & ~mask) | val;
+    }
+    uint64_t acc = 0;
+    uint32_t room = 64, word = 0, maxlen = 0;  // room = 64 - bits of acc in use (> 32 between pixels)
+#pragma unroll
+    for (uint32_t j = 0; j < PACK_PER_THREAD; j++) {
+        const int p = sample_at(cw, j, T()), left = sample_at(lw, j, T()), above = sample_at(uw, j, T());
+        const uint32_t k = (kw[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
+        const int H = max(left, above), L = min(left, above);
+        const int d = p - L, ctx = H - L;  // in range: 0 <= d <= ctx
+        const bool below = d < 0, over = d > ctx;
+        uint32_t val = (uint32_t)(d ^ (d >> 31));        // below: L - p - 1 = ~d ; in range: p - L = d
+        val = over ? (uint32_t)(d - ctx - 1) : val;      // above: p - H - 1
+        // phased-in code of d in [0, ctx] (phase_in): r in m bits or r + right_p in m + 1 bits, behind the flag `1`
+        const uint32_t n = (uint32_t)ctx + 1u;
+        const uint32_t m = 31u - (uint32_t)__clz((int)n);
+        const uint32_t right_p = (2u << m) - n;
+        uint32_t r = (uint32_t)d + (1u << m);
+        r = min(r, r - n);  // r -= n if r >= n
+        const bool lt = r < right_p;
+        const uint32_t code_in = (lt ? (1u << m) : (2u << m) + right_p) + r;  // `1`, then the m or m + 1 bits
+        const uint32_t len_in = m + (lt ? 1u : 2u);
+        // Rice code: `00` below / `01` above, q ones, `0`, k-bit remainder (put_pixel)
+        const uint32_t q = val >> k, rem = val & ((1u << k) - 1u);
+        const uint32_t len_rice = q + k + 3u;
+        const uint32_t rice = ((((over ? 1u : 0u) << (q & 31u)) | ((1u << (q & 31u)) - 1u)) << (k + 1u)) | rem;
+        const bool in_range = !(below || over);
+        const uint32_t code = in_range ? code_in : rice, len = in_range ? len_in : len_rice;
+        maxlen = max(maxlen, len);
+        // append
+        room -= len;
+        acc |= (uint64_t)code << (room & 63u);
+        lrow[min(word, LOCAL_WORDS) * PACK_THREADS] = (uint32_t)(acc >> 32);
+        const bool full = room <= 32u;  // the upper word is complete: it has just been stored for good
+        acc = full ? acc << 32 : acc;
+        room = full ? room + 32u : room;
+        word += full ? 1u : 0u;
+    }
+    if (room < 64u) lrow[min(word, LOCAL_WORDS) * PACK_THREADS] = (uint32_t)(acc >> 32);
+    return maxlen > 32u ? ~0u : word * 32u + (64u - room);
+}
+
 // this workgroup's (tile offset in the launch, plane)
 __device__ __forceinline__ void take_ticket(const FusedArgs &fa, FusedLDS &fl, uint32_t &x, uint32_t &plane) {
-    if (threadIdx.x == 0) fl.ticket_sh = atomicAdd(fa.ticket, 1u);
-    __syncthreads();
-    const uint32_t t = fl.ticket_sh;
+    uint32_t t;
+    if (fa.ticket) {
+        if (threadIdx.x == 0) fl.ticket_sh = atomicAdd(fa.ticket, 1u);
+        __syncthreads();
+        t = fl.ticket_sh;
+    } else {
+        // No counter (launch_pack_g with a null ticket: one-dimensional grid): the workgroup index, in the same (tile, plane)
+        // order.  Only for a pack kernel that has the look-back to itself (the lanes share the tail stream): it relies on
+        // workgroups being started in index order; a look-back that waits in vain still gives up and reports through `error`.
+        t = blockIdx.x;
+    }
     x = t / fa.nplanes;
     plane = t - x * fa.nplanes;
 }
 
 template <typename T>
 __device__ __forceinline__ void pack_tile_fused(TileLDS<T> &tl, const uint8_t *kq, FusedLDS &fl, const T *__restrict__ planes,
-                                                const uint8_t *__restrict__ k_map, const FusedArgs &fa, uint32_t tile, uint32_t plane) {
+                                                const uint8_t *__restrict__ k_map, const FusedArgs &fa, uint32_t tile, uint32_t plane,
+                                                const GroupGeom &gg) {
     uint32_t (&win)[FUSED_WIN_WORDS] = fl.win;
     uint32_t (&lbuf)[LOCAL_WORDS * PACK_THREADS] = fl.lbuf;
     uint32_t (&wsum)[PACK_THREADS / 64] = fl.wsum;
@@ -1292,9 +1566,14 @@ __device__ __forceinline__ void pack_tile_fused(TileLDS<T> &tl, const uint8_t *k
     PSTAMP(4);
 
     // ---- phase 1: this thread's bit string
+    // The branch-free form where it applies: the whole group below the first image row and inside the plane, at most one
+    // first-column pixel in it (whose second neighbour -- two rows up, or above-right in row 1 -- comes from global memory).
+    uint32_t fast_bits = ~0u;
+    if (gg.fast) fast_bits = fast_group<T>(tl, kq, lbuf + threadIdx.x, gg.j0, gg.special);
     LocalBits lb;
     lb.begin(lbuf + threadIdx.x);
-    if (first < end) {
+    lb.total = fast_bits == ~0u ? 0u : fast_bits;
+    if (fast_bits == ~0u && first < end) {
         if (has_header) {  // write_header, format.rs:51-61
             lb.put(0x464C4353u, 32);  // "FLCS"
             lb.put((color << 8) | depth, 16);
@@ -1474,7 +1753,8 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch
     __shared__ FusedLDS fl;
     uint32_t x, plane;
     take_ticket(fa, fl, x, plane);
-    pack_tile_fused<T>(tl, tl.kq, fl, planes, k_map, fa, tile_begin + x, plane);
+    pack_tile_fused<T>(tl, tl.kq, fl, planes, k_map, fa, tile_begin + x, plane,
+                       group_geometry<T>(planes + (uint64_t)plane * fa.npix, tile_begin + x, fa.W, fa.npix));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1527,9 +1807,9 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 5))) __global__ __launch
         constexpr uint32_t CPT = NC / PACK_THREADS;  // contexts per thread
         static_assert(NC == CPT * PACK_THREADS, "thread t lists contexts t, t + PACK_THREADS, ...");
         constexpr uint32_t MAX_ITEMS = SORT_TILE / 64 + 2 * NC;  // a run of L events touches at most L / 64 + 2 blocks
-        static_assert(2 * MAX_ITEMS <= FUSED_WIN_WORDS + LOCAL_WORDS * PACK_THREADS && offsetof(FusedLDS, lbuf) == offsetof(FusedLDS, win) + sizeof(fl.win),
-                      "the block list borrows win + lbuf");
-        uint2 *items = reinterpret_cast<uint2 *>(fl.win);  // {block, first lane of the run | lanes with an event in place << 8}
+        static_assert(2 * MAX_ITEMS <= FUSED_WIN_WORDS + LOCAL_WORDS * PACK_THREADS && offsetof(FusedLDS, win) == offsetof(FusedLDS, lbuf) + sizeof(fl.lbuf),
+                      "the block list borrows lbuf + win");
+        uint2 *items = reinterpret_cast<uint2 *>(fl.lbuf);  // {block, first lane of the run | lanes with an event in place << 8}
         uint32_t ra[CPT], rb[CPT], rbase[CPT];
 #pragma unroll
         for (uint32_t h = 0; h < CPT; h++) {
@@ -1611,7 +1891,136 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 5))) __global__ __launch
     PSTAMP(2);
     __syncthreads();
     PSTAMP(3);
-    if (st < pack_tile_end) pack_tile_fused<T>(tl, kq2, fl, planes, nullptr, fa, st, plane);
+    if (st < pack_tile_end) pack_tile_fused<T>(tl, kq2, fl, planes, nullptr, fa, st, plane, group_geometry<T>(planes + (uint64_t)plane * fa.npix, st, fa.W, fa.npix));
+}
+
+// ------------------------------------------------------------------------------------------
+// pack with k gathered from chain order (k_pack_g): a workgroup takes one tile (sort tile = pack tile).  k of every event
+// lies in k_sorted[slot] (k_assign_serial); the events of a sort tile in one context are one run of slots of that context's
+// chain (tile_off[t][c] .. tile_off[t + 1][c]), and pix_of[slot] is the event's pixel as an offset into the tile.  The
+// workgroup reads its runs -- coalesced: a run is contiguous -- and drops k into the LDS array the pack stage indexes by
+// pixel.  Nothing else of the estimator is left in this kernel.
+// Long runs (more than 32 events) are read 64 events per wave step, up to four steps in flight; short runs one run per
+// lane (a noisy tile has a few hundred runs of a handful of events each).
+// ------------------------------------------------------------------------------------------
+
+struct GSources {
+    const uint8_t *k_sorted;
+    const uint16_t *pix_of;  // offset of the event's pixel in its sort tile
+    const uint32_t *tile_off, *chain_base, *chain_len;
+    uint32_t sort_ntiles;
+};
+
+template <typename T>
+__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 5))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_g(const T *__restrict__ planes, GSources gs, FusedArgs fa,
+                                                                                               uint32_t sort_tile_begin, uint32_t pack_tile_end) {
+    __shared__ TileLDS<T> tl;
+    __shared__ FusedLDS fl;
+    static_assert(SORT_TILE == PACK_TILE, "one workgroup = one sort tile = one pack tile (one look-back per workgroup)");
+    uint8_t *kq = tl.kq;
+    uint32_t x, plane;
+#ifdef FELICS_PACK_STAMPS
+    if (threadIdx.x == 0) fl.t_last = __builtin_amdgcn_s_memtime();
+#endif
+    take_ticket(fa, fl, x, plane);
+    PSTAMP(0);
+    const uint32_t st = sort_tile_begin + x;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr uint32_t NWV = PACK_THREADS / 64;
+    constexpr uint32_t NC = nctx_of<T>();
+    constexpr uint32_t CPT = NC / PACK_THREADS;  // contexts per thread
+    static_assert(NC == CPT * PACK_THREADS, "thread t loads the runs of contexts t, t + PACK_THREADS, ...");
+    const GroupGeom gg = group_geometry<T>(planes + (uint64_t)plane * fa.npix, st, fa.W, fa.npix);
+    static_assert(2 * NC <= FUSED_WIN_WORDS + LOCAL_WORDS * PACK_THREADS && offsetof(FusedLDS, win) == offsetof(FusedLDS, lbuf) + sizeof(fl.lbuf),
+                  "the run table borrows lbuf + win (used by the pack stage only afterwards)");
+    uint32_t *run_a = fl.lbuf, *run_n = fl.lbuf + NC;  // first slot / events of the tile's run in context c
+    {
+        const uint32_t *off0 = gs.tile_off + ((uint64_t)plane * gs.sort_ntiles + st) * NC;
+        const bool last_tile = st + 1 == gs.sort_ntiles;
+        const uint32_t *off1 = last_tile ? gs.chain_len + (uint64_t)plane * NC : off0 + NC;
+        const uint32_t *cb = gs.chain_base + (uint64_t)plane * NC;
+        uint32_t ra[CPT], rb[CPT], rbase[CPT];
+#pragma unroll
+        for (uint32_t h = 0; h < CPT; h++) {
+            const uint32_t c = threadIdx.x + h * PACK_THREADS;
+            ra[h] = off0[c];
+            rb[h] = off1[c];
+            rbase[h] = cb[c];
+        }
+        // the tile's pixels come in on the same round trip as the run table
+        stage_pixels(tl, planes + (uint64_t)plane * fa.npix, st * PACK_TILE, fa.W, fa.npix);
+#pragma unroll
+        for (uint32_t h = 0; h < CPT; h++) {
+            const uint32_t c = threadIdx.x + h * PACK_THREADS;
+            run_a[c] = ra[h] + rbase[h];
+            run_n[c] = rb[h] - ra[h];
+        }
+    }
+    PSTAMP(9);
+    __syncthreads();
+    PSTAMP(10);
+    // wave w takes contexts w, w + 4, w + 8, ...: the contexts that matter in a smooth frame are the first ten.
+    // Runs of up to GATHER_SHORT events are read one run per lane, all of them at once; longer runs 64 events per
+    // wave-load, GATHER_CHUNKS such loads (of any of the wave's runs) in flight together: the stage is one or two memory
+    // round trips per tile, not one per run.
+    constexpr uint32_t GATHER_SHORT = 8, GATHER_CHUNKS = 8;
+#pragma unroll
+    for (uint32_t h = 0; h < NC / (64 * NWV); h++) {
+        const uint32_t c = h * 64 * NWV + lane * NWV + wave;
+        const uint32_t a = run_a[c], n = run_n[c];
+        {  // short runs: lane = run
+            uint32_t kv[GATHER_SHORT], pv[GATHER_SHORT];
+            const bool is_short = n <= GATHER_SHORT;
+            if (__ballot(is_short && n != 0) != 0) {
+#pragma unroll
+                for (uint32_t u = 0; u < GATHER_SHORT; u++) {
+                    kv[u] = pv[u] = 0;
+                    if (is_short && u < n) {
+                        kv[u] = gs.k_sorted[(uint64_t)a + u];
+                        pv[u] = gs.pix_of[(uint64_t)a + u];
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < GATHER_SHORT; u++)
+                    if (is_short && u < n) kq[pv[u]] = (uint8_t)kv[u];
+            }
+        }
+        uint64_t longs = __ballot(n > GATHER_SHORT);
+        uint32_t off = 0;  // events of the first run of `longs` already taken
+        while (longs) {
+            uint32_t base[GATHER_CHUNKS], cnt[GATHER_CHUNKS];
+#pragma unroll
+            for (uint32_t u = 0; u < GATHER_CHUNKS; u++) {  // (wave-uniform: scalar registers)
+                const bool valid = longs != 0;
+                const uint32_t b = valid ? (uint32_t)__builtin_ctzll(longs) : 0u;
+                const uint32_t A = readlane(a, b), N = readlane(n, b);
+                base[u] = A + off;
+                cnt[u] = valid ? min(64u, N - off) : 0u;
+                off += 64;
+                if (valid && off >= N) {
+                    longs &= longs - 1;
+                    off = 0;
+                }
+            }
+            uint32_t kv[GATHER_CHUNKS], pv[GATHER_CHUNKS];
+#pragma unroll
+            for (uint32_t u = 0; u < GATHER_CHUNKS; u++) {
+                kv[u] = pv[u] = 0;
+                if (lane < cnt[u]) {
+                    kv[u] = gs.k_sorted[(uint64_t)base[u] + lane];
+                    pv[u] = gs.pix_of[(uint64_t)base[u] + lane];
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < GATHER_CHUNKS; u++)
+                if (lane < cnt[u]) kq[pv[u]] = (uint8_t)kv[u];
+        }
+    }
+    PSTAMP(2);
+    __syncthreads();
+    PSTAMP(3);
+    if (st < pack_tile_end) pack_tile_fused<T>(tl, kq, fl, planes, nullptr, fa, st, plane, gg);
 }
 
 // Words shared by two tiles (and the last, partly filled word of a plane): OR of the two halves.
@@ -1874,6 +2283,44 @@ template void launch_pack_k<int16_t, uint16_t>(hipStream_t, const int16_t *, con
                                                const uint32_t *, const uint32_t *, const uint32_t *, uint64_t *, uint64_t *, uint32_t *,
                                                uint64_t *, uint32_t *, uint32_t *, uint32_t *, const PackTarget &, const Geometry &,
                                                uint32_t, uint32_t, uint32_t, uint32_t *);
+
+template <typename ET>
+void launch_assign_serial(hipStream_t s, const ET *sorted_e, uint8_t *k_sorted, const uint32_t *block_state,
+                          const uint32_t *total_slots, const uint32_t *block_tag, const uint32_t *partial, uint32_t epoch,
+                          uint32_t slice, const Geometry &g) {
+    const uint32_t nchains = g.nplanes * g.nctx;
+    // persistent: eight workgroups of four waves per CU stride over the blocks (fewer if there cannot be that many blocks)
+    const uint32_t wgs = std::min<uint32_t>(std::max(cdiv(max_event_blocks(g), 256), cdiv(nchains, 256)), 256u * 8u);
+    FELICS_LAUNCH((k_assign_serial<ET>), dim3(wgs), dim3(256), s, sorted_e, block_state, k_sorted, total_slots, block_tag,
+                  reinterpret_cast<const uint2 *>(partial) + (uint64_t)(slice - 1) * nchains, nchains,
+                  (epoch << TAG_SLICE_BITS) | slice);
+}
+template void launch_assign_serial<uint8_t>(hipStream_t, const uint8_t *, uint8_t *, const uint32_t *, const uint32_t *,
+                                            const uint32_t *, const uint32_t *, uint32_t, uint32_t, const Geometry &);
+template void launch_assign_serial<uint16_t>(hipStream_t, const uint16_t *, uint8_t *, const uint32_t *, const uint32_t *,
+                                             const uint32_t *, const uint32_t *, uint32_t, uint32_t, const Geometry &);
+
+template <typename T>
+void launch_pack_g(hipStream_t s, const T *planes, const uint8_t *k_sorted, const uint32_t *pix_of, const uint32_t *tile_off,
+                   const uint32_t *chain_base, const uint32_t *chain_len, uint64_t *status, uint64_t *tile_bitoff,
+                   uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last, uint32_t *error,
+                   const PackTarget &to, const Geometry &g, uint32_t st0, uint32_t st1, uint32_t epoch, uint32_t *ticket) {
+    if (st1 <= st0) return;
+    const FusedArgs fa{status, tile_bitoff, tile_bits, plane_carry, edge_first, edge_last, error,
+                       PlaneOut{to.out, to.slot_stride, to.scratch, to.plane_slot, g.planes_per_image},
+                       g.W, g.H, g.npix, g.pack_tiles, g.color, g.depth, epoch, ticket, g.nplanes};
+    const GSources gs{k_sorted, reinterpret_cast<const uint16_t *>(pix_of), tile_off, chain_base, chain_len, g.sort_tiles};
+    // (the kernel takes its tile from the ticket, or from blockIdx.x of this one-dimensional grid: never from blockIdx.y)
+    FELICS_LAUNCH((k_pack_g<T>), dim3((st1 - st0) * g.nplanes), dim3(PACK_THREADS), s, planes, gs, fa, st0, g.pack_tiles);
+}
+template void launch_pack_g<uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, const uint32_t *, const uint32_t *,
+                                     const uint32_t *, const uint32_t *, uint64_t *, uint64_t *, uint32_t *, uint64_t *,
+                                     uint32_t *, uint32_t *, uint32_t *, const PackTarget &, const Geometry &, uint32_t,
+                                     uint32_t, uint32_t, uint32_t *);
+template void launch_pack_g<int16_t>(hipStream_t, const int16_t *, const uint8_t *, const uint32_t *, const uint32_t *,
+                                     const uint32_t *, const uint32_t *, uint64_t *, uint64_t *, uint32_t *, uint64_t *,
+                                     uint32_t *, uint32_t *, uint32_t *, const PackTarget &, const Geometry &, uint32_t,
+                                     uint32_t, uint32_t, uint32_t *);
 
 void launch_join_edges_tiles(hipStream_t s, const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint32_t *edge_first,
                              const uint32_t *edge_last, const PackTarget &to, const Geometry &g, uint32_t ntiles) {

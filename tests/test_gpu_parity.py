@@ -277,9 +277,11 @@ def test_pack_variants(oracle):
 
     frames = [synth.gray8(1920, 1080, f, "S1") for f in range(16)] + [synth.gray8(1920, 1080, 3, "S2")]
     want = [oracle.compress(f) for f in frames]
-    # default: k computed inside the single-pass pack (k_pack_k); FELICS_ASSIGN=kernel: separate k_assign kernel + k_map
-    for env in ({}, {"FELICS_ASSIGN": "kernel"}, {"FELICS_TWO_PASS": "1"}, {"FELICS_TEST_LOOKBACK_FAIL": "1"},
-                {"FELICS_ASSIGN": "kernel", "FELICS_TEST_LOOKBACK_FAIL": "1"}, {"FELICS_OWN_TAILS": "1"}):
+    # default: k in chain order from k_assign_serial, gathered by the single-pass pack (k_pack_g); FELICS_ASSIGN=inpack: k
+    # computed inside the single-pass pack (k_pack_k); FELICS_ASSIGN=kernel: separate k_assign kernel + k_map
+    for env in ({}, {"FELICS_ASSIGN": "inpack"}, {"FELICS_ASSIGN": "kernel"}, {"FELICS_TWO_PASS": "1"}, {"FELICS_TEST_LOOKBACK_FAIL": "1"},
+                {"FELICS_ASSIGN": "kernel", "FELICS_TEST_LOOKBACK_FAIL": "1"}, {"FELICS_ASSIGN": "inpack", "FELICS_TEST_LOOKBACK_FAIL": "1"},
+                {"FELICS_OWN_TAILS": "1"}, {"FELICS_LANES": "1"}, {"FELICS_LANES": "4", "FELICS_SLICES": "12"}):
         os.environ.update(env)
         os.environ["FELICS_POISON"] = "1"
         try:

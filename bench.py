@@ -201,11 +201,13 @@ def main():
             enc.wait_batch(sub)
     enc.set_profiling(not args.no_stage_timing)
     stage_acc = {}
+    spans = []  # per timed step: HIP-event span from the step's first kernel to its last byte
 
     def finish(sub):  # felics_wait_batch: the batch is complete in HBM when this returns
         enc.wait_batch(sub)
         for k, v in enc.stage_ms().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
+        spans.append(enc.span_ms())
 
     # The K timed steps go through the two-deep submission queue a streaming caller would use: step i + 1 is
     # queued before step i is waited for, so the GPU classifies / scatters the next batch while it packs the
@@ -219,6 +221,7 @@ def main():
             step()
             for k, v in enc.stage_ms().items():
                 stage_acc[k] = stage_acc.get(k, 0.0) + v
+            spans.append(enc.span_ms())
     else:
         inflight = []
         for i in range(args.steps):
@@ -281,6 +284,35 @@ def main():
                           "frac_of_hbm_peak_queued": round(npix * ch / queued / 1e9 / HBM_PEAK_GBS, 5),
                           "calls": reps, "byte_compared_with_oracle": True}
 
+    # Config 5's per-GPU share (64 4K RGB8 frames per submission) rides along too: three steps through the queue.
+    if side is not None:
+        F5 = 64
+        rgbf = torch.empty((F5, H, W, 3), dtype=torch.uint8, device=dev)
+        for i in range(F5):
+            rgbf[i] = synth_torch.rgb8(W, H, first_frame + i, device=dev)
+        outs5 = [torch.empty(int(F5 * npix * 3 * 1.25) + (1 << 20), dtype=torch.uint8, device=dev) for _ in range(depth_q)]
+        o5, l5 = enc.compress_batch_device(rgbf.data_ptr(), F5, W, H, 1, 0, outs5[0].data_ptr(), outs5[0].numel())
+        got = outs5[0][int(o5[3]): int(o5[3] + l5[3])].cpu().numpy().tobytes()
+        if got != oracle.compress(rgbf[3].cpu().numpy()):
+            raise SystemExit("config 5: GPU stream differs from the oracle")
+        for i in range(depth_q):  # every lane's workspace for this shape
+            enc.wait_batch(enc.submit_batch_device(rgbf.data_ptr(), F5, W, H, 1, 0, outs5[i].data_ptr(), outs5[i].numel()))
+        reps5 = 4
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        q = []
+        for i in range(reps5):
+            if len(q) == depth_q:
+                enc.wait_batch(q.pop(0))
+            q.append(enc.submit_batch_device(rgbf.data_ptr(), F5, W, H, 1, 0, outs5[i % depth_q].data_ptr(), outs5[i % depth_q].numel()))
+        while q:
+            enc.wait_batch(q.pop(0))
+        t5 = (time.perf_counter() - t1) / reps5
+        side["config5_share_64_4k_rgb8_frames"] = {"ms_per_step_queued": round(t5 * 1e3, 3), "MPix_s": round(F5 * npix / t5 / 1e6, 1),
+                                                   "frac_of_hbm_peak": round(F5 * npix * 3 / t5 / 1e9 / HBM_PEAK_GBS, 5), "steps": reps5,
+                                                   "byte_compared_with_oracle": True,
+                                                   "note": "one GPU's share of config 5 (512 frames over 8 GPUs); --config 5 --gpus N times the sharded job"}
+        del rgbf, outs5
     # Decode, for the record: the batch's streams through the GPU decoder (one wave per stream: the
     # format is bit-serial per stream) and a sample of them through the host decoder on this box's cores.
     decode = None
@@ -320,11 +352,11 @@ def main():
         ms_per_step = elapsed / steps * 1e3
         value = world * F * npix * steps / elapsed / 1e6  # MPix/s, whole job
         stage_ms = {k: v / steps for k, v in stage_acc.items()}
-        # The dominant kernel: largest summed launch duration per step among the kernels that fill the GPU.  The spine is
-        # left out of the choice (its figures are in pipeline.per_stage): a launch of it is a dependency chain of a few
-        # hundred long-lived waves that runs underneath the other kernels, so its duration is a latency, not a share
-        # of the machine -- and since the pack kernel got faster the two sums are within a few percent of each other.
-        cand = {k: v for k, v in stage_ms.items() if k != "spine"} or stage_ms
+        # The dominant kernel: largest summed launch duration per step, no kernel left out.  (That can be the spine, whose
+        # launches are a dependency chain of a few hundred long-lived waves running underneath the others: its duration is a
+        # latency, not a share of the machine.  roofline.by_kernel lists every stage the same way, so the largest kernel that
+        # fills the GPU can be read next to it.)
+        cand = stage_ms
         dom = max(cand, key=cand.get) if cand else None
         alg_bytes = F * npix * channels * sample_bytes  # 1 B/pixel/channel read (2 for 16-bit), SURVEY.md §8(d)
         # A step launches most kernels once per slice of the images; stage_ms[k] is the sum of the
@@ -368,6 +400,14 @@ def main():
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(per_launch_ms, 4),
                         "launches_per_step": launches, "valu": valu}
+            by_kernel = {}
+            for k, v in stage_ms.items():
+                n = max(1, enc.stage_launches().get(k, 1))
+                if v > 0:
+                    g = alg_bytes / n / (v / n * 1e-3) / 1e9
+                    by_kernel[kernel_of(k)] = {"ms_per_step_sum_of_launches": round(v, 4), "launches_per_step": n,
+                                               "achieved_GBs": round(g, 2), "frac": round(g / HBM_PEAK_GBS, 5)}
+            roofline["by_kernel"] = by_kernel
         # the same figure for every stage (HIP-event brackets; on the low-priority streams they include the wait
         # for free compute resources, which rocprof's kernel begin / end timestamps do not)
         per_stage = {}
@@ -387,11 +427,20 @@ def main():
         line = {
             "metric": "encode MPix/s on 4K 8-bit grayscale batch (bit-exact); % HBM-read roofline",
             "value": round(value, 1), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3),
+            # BASELINE.md section 2's protocol next to the pipelined mean: per step, HIP events from the step's first kernel to
+            # its stream sizes on the host; median over the timed steps.  With several steps in flight a step's span covers
+            # the time it shares the GPU with its neighbours, so the median span exceeds ms_per_step.
+            "median_ms_per_step_event_span": round(sorted(spans)[len(spans) // 2], 3) if spans and not args.no_stage_timing else None,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16" if args.depth16 else "u8", "data": "synthetic",
             "config": {"workload": "batch of %d synthetic %s %dx%d %d-bit %s frames per GPU, resident in HBM"
                                    % (F, "S1-RGB" if args.rgb else args.kind, W, H, 16 if args.depth16 else 8,
                                       "RGB" if args.rgb else "grayscale"),
+                       "content": {"S1": "S1 natural-like synthetic (BASELINE.md section 2): smooth ramps + 3 bits of noise, ~3.6 bits per pixel; "
+                                         "the figure holds for this content only -- S2 noise frames took 3.6x the time per step, "
+                                         "natural-like photographs 1.3-1.4x (profiles/r02/content_sensitivity.txt)",
+                                   "S2": "S2 uniform noise (worst case)", "S3": "S3 flat (best case)"}[args.kind],
                        "baseline_config": args.config, "frames_per_gpu": F, "width": W, "height": H, "channels": channels,
                        "sharding": "frames split across ranks, no collective"},
             "roofline": roofline,

@@ -85,7 +85,7 @@ EXPORTS = [
     "felics_read_header", "felics_write_header",
     "felics_decompress", "felics_strerror", "felics_last_error", "felics_set_profiling",
     "felics_stage_count", "felics_stage_name", "felics_get_stage_ms", "felics_get_stage_launches",
-    "felics_lane_count", "felics_decompress_with_header", "felics_get_stats", "felics_decompress_batch_device",
+    "felics_lane_count", "felics_get_span_ms", "felics_decompress_with_header", "felics_get_stats", "felics_decompress_batch_device",
 ]
 
 _lib = None
@@ -148,6 +148,7 @@ def lib():
     L.felics_stage_name.argtypes = [C.c_int]
     L.felics_stage_name.restype = C.c_char_p
     L.felics_get_stage_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
+    L.felics_get_span_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.felics_get_stage_launches.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
     _lib = L
     return L
@@ -300,6 +301,12 @@ class Encoder:
         buf = (C.c_float * n)()
         lib().felics_get_stage_ms(self._h, buf, n)
         return {lib().felics_stage_name(i).decode(): float(buf[i]) for i in range(n)}
+
+    def span_ms(self):
+        """First kernel -> last byte of the last submission collected (profiling on), in ms."""
+        v = C.c_float(0)
+        lib().felics_get_span_ms(self._h, C.byref(v))
+        return float(v.value)
 
     def stage_launches(self):
         n = lib().felics_stage_count()

@@ -29,8 +29,8 @@ static_assert(ST_COUNT <= FELICS_MAX_STAGES, "felics.h promises at most FELICS_M
 constexpr int SLICES = 12;              // at most; a submission uses lane.nslices of them
 constexpr int EV_PAIRS = SLICES + 2;     // launches of one stage per sub-batch that can be timed
 constexpr int MAX_LANES = 4;            // upper bound of the submissions in flight (felics_submit_batch_device), each with streams and workspace of its own
-constexpr int DEFAULT_LANES = 3;        // what a context uses unless FELICS_LANES says otherwise: with three, the spine chains (the one
-                                        // sequential part, ~3 ms per 4K frame) of two submissions run side by side while a third is in its front end
+constexpr int DEFAULT_LANES = 2;        // what a context uses unless FELICS_LANES says otherwise (measured round 3: 2 lanes x 4 slices 3.03-3.06 ms per step,
+                                        // 3 lanes x 3 slices 2.97-3.16, 4 lanes 3.18-3.47: the kernels are issue-bound, so more of them side by side gain nothing)
 int lanes_from_env() {
     if (const char *e = getenv("FELICS_LANES")) return std::max(1, std::min(atoi(e), MAX_LANES));
     return DEFAULT_LANES;
@@ -55,6 +55,7 @@ struct Lane {
     hipEvent_t ev[ST_COUNT][EV_PAIRS][2] = {};  // profiling: one start/stop pair per launch of a stage
     int ev_used[ST_COUNT] = {};                  // pairs used by the current sub-batch
     hipEvent_t sized = nullptr;       // stream sizes have landed in h_sizes
+    hipEvent_t span_begin = nullptr, span_end = nullptr;  // profiling: in front of the sub-batch's first kernel / behind its last byte
     uint64_t *h_sizes = nullptr;      // pinned: image_bytes[n] followed by image_off[n + 1]
     size_t h_sizes_cap = 0;
     DevBuf planes, counts, chain_len, chain_base, chain_prog, scalars, sorted_e, pix_of, k_map, k_sorted, block_state, group_bits,
@@ -92,7 +93,7 @@ struct felics_ctx {
     // spine closely.  With two submissions in flight the other batch keeps the GPU busy, and every slice costs
     // a launch and a hand-over per stage: few slices are faster there (measured: 12 -> 5.3, 6 -> 5.1, 3 -> 4.8 ms).
     int slices_blocking = 6;    // FELICS_SLICES
-    int slices_queued = 3;      // FELICS_SLICES_QUEUED
+    int slices_queued = 4;      // FELICS_SLICES_QUEUED
     bool stripe = false;        // FELICS_PIPELINE=stripe: 8-bit frames with fixed output slots go through the fused tile kernel
                                 // (felics_stripe.hip) instead of the multi-kernel pipeline.  Measured slower so far,
                                 // hence opt-in; a hand-off of that kernel that gives up moves the context back for good
@@ -104,7 +105,11 @@ struct felics_ctx {
     //   kernel:           k_assign scatters k to a byte per pixel in HBM (k_map), which the pack stages (round 1)
     enum AssignMode { ASSIGN_GATHER = 0, ASSIGN_INPACK = 1, ASSIGN_KERNEL = 2 };
     int assign_mode = ASSIGN_GATHER;
-    bool pack_tickets = true;   // k_pack_g takes its tiles from a ticket counter (FELICS_TICKETS=0: from the workgroup index; needs the shared tail stream)
+    // k_pack_g takes its tiles from the workgroup index: the lanes share the tail stream, so one pack kernel has the look-back
+    // to itself.  A ticket counter (FELICS_TICKETS=1, and always with FELICS_OWN_TAILS) is one memory-side atomic per tile on one
+    // address -- 130 000 per step at the ~88 per microsecond one address sustains (MI355X_MICROARCH.md, dequeue): alone that
+    // is 1.5 ms per step (measured: the pack launches of a step 1.59 ms with the counter, 1.26 ms without).
+    bool pack_tickets = false;
     bool two_pass = false;      // FELICS_TWO_PASS=1, or a look-back of the single-pass pack gave up once: lengths + pack kernels
     bool test_timeout = false;  // FELICS_TEST_TIMEOUT=1: every wait for the GPU reports a time-out (tests of the failed state)
     bool test_stripe_fail = false; // FELICS_TEST_STRIPE_FAIL=1: pretend the first fused-kernel submission gave up (tests)
@@ -121,6 +126,7 @@ struct felics_ctx {
     std::string err;
     bool profiling = false;
     float stage_ms[ST_COUNT] = {};
+    float span_ms = 0.f;        // profiling: first kernel -> sizes on the host, of the last submission collected
     int stage_launches[ST_COUNT] = {};
     DevBuf in, out;  // staging of the host-pointer entry points
     DevBuf dec_meta, dec_planes;  // GPU decoder: offsets | lens | status of a batch; Y / Co / Cg planes of RGB streams
@@ -471,6 +477,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     l.h_sizes[g.nimages] = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&l.h_sizes[g.nimages], d_error, 4, hipMemcpyDeviceToHost, tl));
     HIP_TRY(ctx, hipEventRecord(l.sized, tl));
+    if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(l.span_end, tl));
     return FELICS_OK;
 }
 
@@ -561,6 +568,7 @@ int run_stripe(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     l.h_sizes[g.nimages] = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&l.h_sizes[g.nimages], (uint32_t *)l.s_ctl.p + STRIPE_CTL_ERROR, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipEventRecord(l.sized, s));
+    if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(l.span_end, s));
     if (a.stamps) {
         std::vector<uint64_t> h(ntt * STRIPE_STAMPS);
         HIP_TRY(ctx, hipMemcpy(h.data(), a.stamps, ntt * STRIPE_STAMPS * 8, hipMemcpyDeviceToHost));
@@ -663,6 +671,7 @@ int run_wide(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(l.h_sizes, l.image_bytes.p, (size_t)g.nimages * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipEventRecord(l.sized, s));
+    if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(l.span_end, s));
     return FELICS_OK;
 }
 
@@ -690,6 +699,8 @@ int pack_exact(felics_ctx *ctx, Lane &l, uint8_t *d_out) {
 
 void collect_timing(felics_ctx *ctx, Lane &l) {
     if (!ctx->profiling) return;
+    ctx->span_ms = 0.f;
+    (void)hipEventElapsedTime(&ctx->span_ms, l.span_begin, l.span_end);
     for (int i = 0; i < ST_COUNT; i++) {
         ctx->stage_ms[i] = 0.f;  // sum of the launches' durations (launches overlap: the sum can exceed wall time)
         ctx->stage_launches[i] = 0;
@@ -740,6 +751,8 @@ int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const v
     l.first_image = first;
     const uint8_t *src = (const uint8_t *)d_pixels + first * frame_bytes;
     l.d_planes = src;
+    if (ctx->profiling)  // on the stream the sub-batch's first kernel runs on
+        HIP_TRY(ctx, hipEventRecord(l.span_begin, wide || getenv("FELICS_SERIAL") ? l.stream : l.front));
     l.ran_stripe = !wide && (planes == 3 ? stripe_fits<int16_t>(ctx, w, slot) : stripe_fits<uint8_t>(ctx, w, slot));
     if (planes == 3) {
         if ((rc = reserve(ctx, l.planes, (size_t)g.nplanes * npix * (wide ? 4 : 2) + STAGE_PAD)) != 0) return rc;
@@ -940,7 +953,8 @@ int felics_ctx_create(int device, felics_ctx **out) {
     ctx->test_lookback = getenv("FELICS_TEST_LOOKBACK_FAIL") != nullptr;
     if (const char *e = getenv("FELICS_ASSIGN"))
         ctx->assign_mode = strcmp(e, "kernel") == 0 ? felics_ctx::ASSIGN_KERNEL : strcmp(e, "inpack") == 0 ? felics_ctx::ASSIGN_INPACK : felics_ctx::ASSIGN_GATHER;
-    if (const char *e = getenv("FELICS_TICKETS")) ctx->pack_tickets = atoi(e) != 0 || getenv("FELICS_OWN_TAILS") != nullptr;
+    if (const char *e = getenv("FELICS_TICKETS")) ctx->pack_tickets = atoi(e) != 0;
+    if (getenv("FELICS_OWN_TAILS")) ctx->pack_tickets = true;
     ctx->test_stripe_fail = getenv("FELICS_TEST_STRIPE_FAIL") != nullptr;
     ctx->test_timeout = getenv("FELICS_TEST_TIMEOUT") != nullptr;
     if (const char *e = getenv("FELICS_PIPELINE")) ctx->stripe = strcmp(e, "stripe") == 0;
@@ -984,6 +998,7 @@ int felics_ctx_create(int device, felics_ctx **out) {
             ok = ok && hipEventCreateWithFlags(&l.assign_done[q], hipEventDisableTiming) == hipSuccess;
         }
         ok = ok && hipEventCreateWithFlags(&l.sized, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreate(&l.span_begin) == hipSuccess && hipEventCreate(&l.span_end) == hipSuccess;
         for (int i = 0; i < ST_COUNT && ok; i++)
             for (int k = 0; k < EV_PAIRS && ok; k++)
                 for (int j = 0; j < 2 && ok; j++) ok = hipEventCreate(&l.ev[i][k][j]) == hipSuccess;
@@ -1023,6 +1038,8 @@ void felics_ctx_destroy(felics_ctx *ctx) {
                 for (int j = 0; j < 2; j++)
                     if (l.ev[i][k][j]) (void)hipEventDestroy(l.ev[i][k][j]);
         if (l.sized) (void)hipEventDestroy(l.sized);
+        if (l.span_begin) (void)hipEventDestroy(l.span_begin);
+        if (l.span_end) (void)hipEventDestroy(l.span_end);
         for (int q = 0; q < SLICES; q++) {
             if (l.slice_done[q]) (void)hipEventDestroy(l.slice_done[q]);
             if (l.spine_done[q]) (void)hipEventDestroy(l.spine_done[q]);
@@ -1331,6 +1348,12 @@ int felics_get_stage_launches(const felics_ctx *ctx, int *launches, int cap) {
 }
 
 const char *felics_stage_name(int stage) { return stage >= 0 && stage < ST_COUNT ? kStageNames[stage] : ""; }
+
+int felics_get_span_ms(const felics_ctx *ctx, float *ms) {
+    if (!ctx || !ms) return FELICS_E_INVALID_ARGUMENT;
+    *ms = ctx->span_ms;
+    return FELICS_OK;
+}
 
 int felics_get_stage_ms(const felics_ctx *ctx, float *ms, int cap) {
     if (!ctx || !ms) return FELICS_E_INVALID_ARGUMENT;

@@ -96,14 +96,14 @@ __global__ __launch_bounds__(256) void k_hist(const T *__restrict__ planes, uint
     // (SQ_LDS_BANK_CONFLICT 84 M of SQ_LDS_IDX_ACTIVE 103 M cycles per step).
     constexpr uint32_t NC = nctx_of<T>();
     constexpr uint32_t COPIES = 4096 / NC / 4;  // 16 KB of LDS per workgroup either way: 4 (u8) or 2 (i16)
-    __shared__ uint32_t hist[4][COPIES][NC];
+    __shared__ uint32_t hist[4][NC * COPIES];  // [wave][ctx * COPIES + copy]: the copies of a context lie in different banks
     // (wave-uniform, and said so: the tile, its bounds and the trip bookkeeping then live in scalar registers instead of
     // vector registers under exec masks -- without it three quarters of this kernel's instructions were mask handling)
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
     const uint32_t tile = blockIdx.x * 4 + wave;
     const uint32_t plane = blockIdx.y;
-    for (uint32_t c = lane; c < NC * COPIES; c += 64) hist[wave][0][c] = 0;
-    uint32_t *my_hist = hist[wave][lane % COPIES];
+    for (uint32_t c = lane; c < NC * COPIES; c += 64) hist[wave][c] = 0;
+    uint32_t *my_hist = hist[wave] + lane % COPIES;
     __builtin_amdgcn_wave_barrier();
     if (tile < ntiles) {
         const T *pl = planes + (uint64_t)plane * npix;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_hist(const T *__restrict__ planes, uint
                         classify_loaded4(now, pc);
 #pragma unroll
                         for (uint32_t u = 0; u < 4; u++)
-                            if (pc[u].cls != CLS_IN) atomicAdd(&my_hist[pc[u].ctx], 1u);
+                            if (pc[u].cls != CLS_IN) atomicAdd(&my_hist[pc[u].ctx * COPIES], 1u);
                     } else {  // (a trip that crosses a row end, or lies in the first row: the general neighbour rule)
                         Coord xy;
                         xy.set(r0 + lane, W);
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_hist(const T *__restrict__ planes, uint
                             const uint32_t i = r0 + u * 64 + lane;
                             if (i < end && i >= 2) {
                                 const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
-                                if (pc.cls != CLS_IN) atomicAdd(&my_hist[pc.ctx], 1u);
+                                if (pc.cls != CLS_IN) atomicAdd(&my_hist[pc.ctx * COPIES], 1u);
                             }
                             xy.advance(64, W);
                         }
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_hist(const T *__restrict__ planes, uint
         for (uint32_t c = lane; c < NC; c += 64) {
             uint32_t n = 0;
 #pragma unroll
-            for (uint32_t q = 0; q < COPIES; q++) n += hist[wave][q][c];
+            for (uint32_t q = 0; q < COPIES; q++) n += hist[wave][c * COPIES + q];
             dst[c] = n;
         }
     }

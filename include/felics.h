@@ -102,7 +102,7 @@ int felics_compress_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels
 
 /* The same submission in two halves, for callers that encode batch after batch: felics_submit_batch_device
  * queues the work and returns, felics_wait_batch(ticket) blocks until that batch is complete and fills
- * offsets / lens.  Up to felics_lane_count() (2) submissions can be in flight, each with its own d_out;
+ * offsets / lens.  Up to felics_lane_count() submissions can be in flight, each with its own d_out;
  * tickets must be waited for in the order they were handed out.  While the GPU is finishing one batch (its
  * last pack slices) it already classifies, scatters and replays the estimator of the next one, which hides
  * the latency-bound head and tail of a batch.  The synchronous entry points refuse to run
@@ -173,6 +173,9 @@ int felics_stage_count(void);
 const char *felics_stage_name(int stage);
 int felics_get_stage_ms(const felics_ctx *ctx, float *ms, int cap);
 int felics_get_stage_launches(const felics_ctx *ctx, int *launches, int cap);
+/* The same submission from its first kernel to its last byte (stream sizes on the host): one HIP event in front of the first
+ * launch, one behind the size copy, on the streams they run on -- BASELINE.md section 2's per-step span. */
+int felics_get_span_ms(const felics_ctx *ctx, float *ms);
 /* Submissions that can be in flight at a time (felics_submit_batch_device). */
 int felics_lane_count(void);
 

@@ -21,6 +21,8 @@
 // Integer work only: no MFMA.  Wave = 64 lanes everywhere.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "felics_device.h"
 #include "felics_kernels.h"
@@ -465,17 +467,26 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
 
 constexpr uint32_t SPINE_BATCH = 64;  // blocks fetched per step: lane j holds block j
 
+// LDS of the one-wave walk (k_spine, and the short chains of k_spine2)
 template <typename ET>
-__global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, uint32_t *__restrict__ block_state,
+struct SpineSingleLDS {
+    static constexpr uint32_t DW = 64 * sizeof(ET) / 4;  // dwords per block
+    uint32_t stage[SPINE_BATCH * DW];       // the batch's events
+    uint32_t bsum[(SPINE_BATCH + 1) * 8];   // [block][k]: sum of the block's lengths for k = 0..5
+    uint32_t rec[SPINE_BATCH * 8];          // [block][k]: state at the start of the block
+};
+
+template <typename ET>
+__device__ __forceinline__ void spine_single(SpineSingleLDS<ET> &sh, const ET *__restrict__ sorted_e, uint32_t *__restrict__ block_state,
                                               const uint32_t *__restrict__ chain_base,
                                               const uint32_t *__restrict__ chain_len, uint32_t nchains,
                                               const uint32_t *__restrict__ tile_off, uint32_t ntiles, uint32_t t_end,
                                               uint32_t *__restrict__ chain_prog, uint32_t *__restrict__ block_tag,
                                               uint2 *__restrict__ partial, uint32_t stamp) {
     constexpr uint32_t DW = 64 * sizeof(ET) / 4;  // dwords per block
-    __shared__ uint32_t stage[SPINE_BATCH * DW];          // the batch's events
-    __shared__ uint32_t bsum[(SPINE_BATCH + 1) * 8];      // [block][k]: sum of the block's lengths for k = 0..5
-    __shared__ uint32_t rec[SPINE_BATCH * 8];             // [block][k]: state at the start of the block
+    uint32_t (&stage)[SPINE_BATCH * DW] = sh.stage;
+    uint32_t (&bsum)[(SPINE_BATCH + 1) * 8] = sh.bsum;
+    uint32_t (&rec)[SPINE_BATCH * 8] = sh.rec;
     // Workgroup w -> (context w / nplanes, plane w % nplanes): the long chains (small contexts) of all
     // planes start first and land on different XCDs (workgroups are dealt round-robin over the XCDs).
     if (blockIdx.x >= nchains) return;
@@ -530,7 +541,7 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
             reinterpret_cast<uint4 *>(bsum)[lane * 2] = make_uint4(B01 & 0xFFFFu, B01 >> 16, B23 & 0xFFFFu, B23 >> 16);
             reinterpret_cast<uint4 *>(bsum)[lane * 2 + 1] = make_uint4(B45 & 0xFFFFu, B45 >> 16, 0u, 0u);
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();  // (one wave: its own LDS traffic in order)
         // prefetch the next batch while this one is walked
         if (bb + SPINE_BATCH + lane < nblocks) {
 #pragma unroll
@@ -579,14 +590,14 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
             Sv += Bv;
             Bv = Bnext;
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();  // (one wave: its own LDS traffic in order)
         if (lane < nb) {
             const uint4 hi = reinterpret_cast<const uint4 *>(rec)[lane * 2 + 1];
             states[(uint64_t)(bb + lane) * 2] = reinterpret_cast<const uint4 *>(rec)[lane * 2];
             states[(uint64_t)(bb + lane) * 2 + 1] = make_uint4(hi.x, hi.y, 0u, 0u);
             tags[bb + lane] = stamp;  // resolved in this launch (a block is resolved exactly once)
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();  // (one wave: its own LDS traffic in order)
     }
     if (lane < 6) prog[1 + lane] = Sv;
     if (lane == 6) prog[0] = nblocks;
@@ -594,6 +605,263 @@ __global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, u
     // Events that are in place but do not fill a block yet: publish the block's start state and, in this
     // launch's own list (never overwritten by a later launch), which block it is and how many of its
     // events exist, so k_assign can serve them now.  The block itself is resolved by a later launch.
+    if (!final_slice && (avail & 63u) != 0) {
+        const uint32_t s0 = readlane(Sv, 0), s1 = readlane(Sv, 1), s2 = readlane(Sv, 2);
+        const uint32_t s3 = readlane(Sv, 3), s4 = readlane(Sv, 4), s5 = readlane(Sv, 5);
+        if (lane == 0) {
+            states[(uint64_t)nblocks * 2] = make_uint4(s0, s1, s2, s3);
+            states[(uint64_t)nblocks * 2 + 1] = make_uint4(s4, s5, 0u, 0u);
+            partial[chain] = make_uint2((base >> 6) + nblocks, avail & 63u);
+        }
+    }
+}
+
+
+template <typename ET>
+__global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, uint32_t *__restrict__ block_state,
+                                              const uint32_t *__restrict__ chain_base,
+                                              const uint32_t *__restrict__ chain_len, uint32_t nchains,
+                                              const uint32_t *__restrict__ tile_off, uint32_t ntiles, uint32_t t_end,
+                                              uint32_t *__restrict__ chain_prog, uint32_t *__restrict__ block_tag,
+                                              uint2 *__restrict__ partial, uint32_t stamp) {
+    __shared__ SpineSingleLDS<ET> sh;
+    spine_single<ET>(sh, sorted_e, block_state, chain_base, chain_len, nchains, tile_off, ntiles, t_end, chain_prog, block_tag, partial, stamp);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_spine2: the same walk with HELPER waves.  In k_spine the walker spends two thirds of a halving period building what
+// it needs to locate the halving: the block's per-event prefix sums (lengths, three packed DPP scans) and, once per batch,
+// the block sums.  None of that depends on the estimator's state, so three more waves of the workgroup produce it ahead of
+// the walker -- for EVERY block, although only one block in three holds a halving: they have nothing else to do -- and
+// hand it over through LDS, SP_BATCH blocks at a time, double-buffered, one workgroup barrier per batch:
+//   helpers, batch t:  pref[t & 1][j][lane] = packed inclusive prefix sums of block j's six length vectors,
+//                      bsum[t & 1][j][k]    = the block's sums; and the block-start states the walker left for batch t - 2
+//                      (rec) go out to block_state / block_tag;
+//   walker,  batch t - 1: per block one LDS read, one add, one compare (as before); in a block with a halving three LDS
+//                      reads of its prefix sums and a search that compares them, still packed, with packed thresholds
+//                      theta_k = P_k(last halving) + max(1025 - S_k, 0): min(S + P) > 1024  <=>  P_k >= theta_k for all k.
+// Chains with fewer than SP_SMALL blocks to walk in this launch take the one-wave path (waves 1-3 leave at once).
+// ------------------------------------------------------------------------------------------
+
+#ifdef FELICS_SPINE_STAMPS
+// Diagnostic build only: s_memtime ticks of the walker of ONE chain (context 1 of plane 0, the longest of an S1 frame),
+// summed by phase: [0] waiting at the batch barrier, [1] block steps without a halving, [2] prefix-sum reads + first
+// threshold round up to the ballot, [3] the rest of the halving rounds, [4] halvings, [5] blocks, [6] batches, [7] total.
+__device__ unsigned long long g_spine_stamps[8];
+#define SSTAMP(i)                                                      \
+    do {                                                               \
+        if (stamped) {                                                 \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+            st_acc[i] += now_ - st_last;                               \
+            st_last = now_;                                            \
+        }                                                              \
+    } while (0)
+#define SCOUNT(i) do { if (stamped) st_acc[i]++; } while (0)
+extern "C" __attribute__((visibility("default"))) int felics_debug_spine_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spine_stamps), sizeof(g_spine_stamps)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_spine_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define SSTAMP(i)
+#define SCOUNT(i)
+#endif
+
+constexpr uint32_t SP_BATCH = 16;   // blocks per hand-over
+constexpr uint32_t SP_HELPERS = 3;
+constexpr uint32_t SP_SMALL = 24;   // blocks
+
+typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
+// both 16-bit halves of p >= the halves of theta
+__device__ __forceinline__ bool pk_all_ge(uint32_t p, uint32_t theta) {
+    const pk_u16 a = __builtin_bit_cast(pk_u16, p), b = __builtin_bit_cast(pk_u16, theta);
+    const pk_u16 m = __builtin_elementwise_max(a, b);
+    return __builtin_bit_cast(uint32_t, m) == p;
+}
+
+template <typename ET>
+__global__ __launch_bounds__(256) void k_spine2(const ET *__restrict__ sorted_e, uint32_t *__restrict__ block_state,
+                                                const uint32_t *__restrict__ chain_base,
+                                                const uint32_t *__restrict__ chain_len, uint32_t nchains,
+                                                const uint32_t *__restrict__ tile_off, uint32_t ntiles, uint32_t t_end,
+                                                uint32_t *__restrict__ chain_prog, uint32_t *__restrict__ block_tag,
+                                                uint2 *__restrict__ partial, uint32_t stamp) {
+    struct Multi {
+        uint32_t pref[2][SP_BATCH][3][64];       // [buffer][block][register][lane]
+        uint32_t bsum[2][(SP_BATCH + 1) * 8];    // [buffer][block][k]
+    };
+    union Shared {
+        SpineSingleLDS<ET> single;
+        Multi multi;
+    };
+    __shared__ Shared sh;
+    if (blockIdx.x >= nchains) return;
+    constexpr uint32_t NC = nctx_of<ET>();
+    const uint32_t nplanes = nchains / NC;
+    const uint32_t ctx = blockIdx.x / nplanes, plane = blockIdx.x % nplanes;
+    const uint32_t chain = plane * NC + ctx;
+    // (wave-uniform values loaded from memory, and said so: the walk's loop control then runs on the scalar unit)
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)chain_len[chain]);
+    if (n == 0) return;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t l7 = lane & 7u;
+    const bool final_slice = t_end >= ntiles;
+    const uint32_t avail = final_slice ? n : (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_off[((uint64_t)plane * ntiles + t_end) * NC + ctx]);  // events in place
+    const uint32_t nblocks = final_slice ? (n + 63u) >> 6 : avail >> 6;
+    uint32_t *prog = chain_prog + (uint64_t)chain * 8;  // [0] next block, [1..6] state
+    const uint32_t first_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)prog[0]);
+    if (first_block >= nblocks || nblocks - first_block < SP_SMALL) {
+        if (wave == 0)
+            spine_single<ET>(sh.single, sorted_e, block_state, chain_base, chain_len, nchains, tile_off, ntiles, t_end, chain_prog, block_tag,
+                             partial, stamp);
+        return;
+    }
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)chain_base[chain]);  // multiple of 64
+    const ET *ev_src = sorted_e + base;
+    uint4 *states = reinterpret_cast<uint4 *>(block_state) + (uint64_t)(base >> 6) * 2;
+    uint32_t *tags = block_tag + (base >> 6);
+    const uint32_t nbatches = (nblocks - first_block + SP_BATCH - 1) / SP_BATCH;
+    Multi &m = sh.multi;
+
+    if (wave != 0) {
+        // ---- helpers: helper h takes blocks h, h + 3, ... of every batch; the events of batch t + 1 are loaded while batch t is summed
+        const uint32_t h = wave - 1;
+        constexpr uint32_t PER = (SP_BATCH + SP_HELPERS - 1) / SP_HELPERS;
+        uint32_t ev[PER], nxt[PER];
+        auto load_batch = [&](uint32_t t, uint32_t (&dst)[PER]) {
+#pragma unroll
+            for (uint32_t u = 0; u < PER; u++) {
+                const uint32_t j = h + u * SP_HELPERS, b = first_block + t * SP_BATCH + j;
+                dst[u] = 0;
+                if (t < nbatches && j < SP_BATCH && b < nblocks) dst[u] = (uint32_t)ev_src[(uint64_t)b * 64 + lane];
+            }
+        };
+        load_batch(0, ev);
+        for (uint32_t t = 0; t < nbatches + 1; t++) {
+            load_batch(t + 1, nxt);
+            const uint32_t buf = t & 1u;
+            if (t < nbatches) {
+#pragma unroll
+                for (uint32_t u = 0; u < PER; u++) {
+                    const uint32_t j = h + u * SP_HELPERS;
+                    if (j < SP_BATCH) {  // (blocks past the chain's end: their sums are never used)
+                        uint32_t l01, l23, l45;
+                        packed_lengths(ev[u], l01, l23, l45);
+                        const uint32_t p01 = wave_incl_scan(l01), p23 = wave_incl_scan(l23), p45 = wave_incl_scan(l45);
+                        m.pref[buf][j][0][lane] = p01;
+                        m.pref[buf][j][1][lane] = p23;
+                        m.pref[buf][j][2][lane] = p45;
+                        const uint32_t s01 = readlane(p01, 63), s23 = readlane(p23, 63), s45 = readlane(p45, 63);
+                        if (lane < 8) {
+                            const uint32_t pair = lane < 2 ? s01 : lane < 4 ? s23 : s45;
+                            m.bsum[buf][j * 8 + lane] = lane < 6 ? (pair >> ((lane & 1u) << 4)) & 0xFFFFu : 0u;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < PER; u++) ev[u] = nxt[u];
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- the walker
+    uint32_t Sv = l7 < 6 ? prog[1 + l7] : 0u;  // lane l holds S[l & 7] (entries 6, 7: zero)
+    asm volatile("; state in %0" : "+v"(Sv));
+    __builtin_amdgcn_s_setprio(3);  // a chain is one long dependent instruction stream: never make it wait for issue
+    const uint32_t sh16 = (l7 & 1u) << 4;
+#ifdef FELICS_SPINE_STAMPS
+    const bool stamped = ctx == 1 && plane == 0;
+    unsigned long long st_acc[8] = {}, st_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_last;
+#endif
+    __syncthreads();  // iteration 0: the helpers' first batch
+    SSTAMP(0);
+    // The block-start states go out eight blocks at a time: the state vector is replicated in every group of eight lanes
+    // (lane l holds S[l & 7]), so the lanes 8 u .. 8 u + 7 keep a copy of it at the start of the group's block u -- one
+    // select per block, no memory operation in the walk -- and every eight blocks one coalesced 256-byte store carries
+    // eight records (block_state: 8 words per block), one more their tags.  Nothing in the walk waits for these stores.
+    uint32_t *state_words = reinterpret_cast<uint32_t *>(states);
+    for (uint32_t t = 1; t <= nbatches; t++) {
+        const uint32_t buf = (t - 1) & 1u;
+        const uint32_t bb = first_block + (t - 1) * SP_BATCH;
+        const uint32_t nb = min(SP_BATCH, nblocks - bb);
+        const uint32_t *bs = m.bsum[buf];
+        uint32_t Bv = bs[l7];
+        for (uint32_t j0 = 0; j0 < nb; j0 += 8) {
+            uint32_t held = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) {
+                const uint32_t j = j0 + u;
+                if (j < nb) {
+                    const uint32_t Bnext = bs[(j + 1) * 8 + l7];  // look-ahead: independent of the state (row SP_BATCH: never used)
+                    held = (lane >> 3) == u ? Sv : held;
+                    const uint32_t Ev = Sv + Bv;
+                    const uint32_t over = (uint32_t)__ballot(Ev > 1024u) & 0x3Fu;
+                    SCOUNT(5);
+                    if (over != 0x3Fu) {  // some counter still <= 1024 at the end of the block: no halving inside
+                        Sv = Ev;
+                        Bv = Bnext;
+                        SSTAMP(1);
+                    } else {
+                        SSTAMP(1);
+                        // a halving happens inside this block
+                        const uint32_t p01 = m.pref[buf][j][0][lane], p23 = m.pref[buf][j][1][lane], p45 = m.pref[buf][j][2][lane];
+                        uint32_t basev = 0;          // P_k at the block's last halving so far (state-vector layout, like Sv)
+                        uint64_t live = ~0ull;       // lanes behind the last halving
+                        while (true) {
+                            // theta_k = base_k + max(1025 - S_k, 0), two to a register: lane 0 -> k = 0, 1; lane 2 -> 2, 3; lane 4 -> 4, 5
+                            const uint32_t theta = basev + (uint32_t)max(1025 - (int)Sv, 0);
+                            const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)theta, 0x101, 0xF, 0xF, true);  // row_shl:1
+                            const uint32_t th2 = theta | (up << 16);
+                            const uint32_t T01 = readlane(th2, 0), T23 = readlane(th2, 2), T45 = readlane(th2, 4);
+                            const uint64_t hm = __ballot(pk_all_ge(p01, T01)) & __ballot(pk_all_ge(p23, T23)) & __ballot(pk_all_ge(p45, T45)) & live;
+                            // (the block-level test said a halving exists, and the loop is only re-entered when the end state says
+                            // there is another: hm is never empty here -- but a wave that spins on a broken invariant takes the GPU
+                            // with it)
+                            if (hm == 0) break;
+                            SSTAMP(2);
+                            SCOUNT(4);
+                            const uint32_t f = (uint32_t)__builtin_ctzll(hm);
+                            const uint32_t q01 = readlane(p01, f), q23 = readlane(p23, f), q45 = readlane(p45, f);
+                            const uint32_t qv = l7 < 2 ? q01 : l7 < 4 ? q23 : q45;
+                            const uint32_t Pf = l7 < 6 ? (qv >> sh16) & 0xFFFFu : 0u;
+                            Sv = (Sv + Pf - basev) >> 1;  // x /= 2 on every counter (parameter_selection.rs:62)
+                            basev = Pf;
+                            if (f == 63) break;
+                            live = ~0ull << (f + 1);
+                            // another halving in this block only if the end state still has all six counters above 1024
+                            if (((uint32_t)__ballot(Sv + Bv - basev > 1024u) & 0x3Fu) != 0x3Fu) break;
+                        }
+                        Sv += Bv - basev;
+                        Bv = Bnext;
+                        SSTAMP(3);
+                    }
+                }
+            }
+            // eight records (fewer at the chain's end): lane l -> word l & 7 of block j0 + l / 8
+            const uint32_t nrec = min(8u, nb - j0);
+            if ((lane >> 3) < nrec) state_words[(uint64_t)(bb + j0) * 8 + lane] = l7 < 6 ? held : 0u;
+            if (lane < nrec) tags[bb + j0 + lane] = stamp;  // resolved in this launch (a block is resolved exactly once)
+        }
+        SCOUNT(6);
+        __syncthreads();
+        SSTAMP(0);
+    }
+#ifdef FELICS_SPINE_STAMPS
+    if (stamped && lane == 0) {
+        for (int i = 0; i < 7; i++) atomicAdd(&g_spine_stamps[i], st_acc[i]);
+        atomicAdd(&g_spine_stamps[7], __builtin_amdgcn_s_memtime() - st_begin);
+    }
+#endif
+    if (lane < 6) prog[1 + lane] = Sv;
+    if (lane == 6) prog[0] = nblocks;
+    // Events that are in place but do not fill a block yet: publish the block's start state and which block it is (k_spine)
     if (!final_slice && (avail & 63u) != 0) {
         const uint32_t s0 = readlane(Sv, 0), s1 = readlane(Sv, 1), s2 = readlane(Sv, 2);
         const uint32_t s3 = readlane(Sv, 3), s4 = readlane(Sv, 4), s5 = readlane(Sv, 5);
@@ -2143,10 +2411,20 @@ void launch_spine(hipStream_t s, const ET *sorted_e, uint32_t *block_state, cons
                   const uint32_t *chain_len, const uint32_t *tile_off, uint32_t t_end, uint32_t *chain_prog,
                   uint32_t *block_tag, uint32_t *partial, uint32_t epoch, uint32_t slice, const Geometry &g) {
     const uint32_t nchains = g.nplanes * g.nctx;
-    FELICS_LAUNCH((k_spine<ET>), dim3(nchains), dim3(64), s, sorted_e, block_state, chain_base, chain_len,
-                       nchains, tile_off, g.sort_tiles, t_end, chain_prog, block_tag,
-                       reinterpret_cast<uint2 *>(partial) + (uint64_t)(slice - 1) * nchains,
-                       (epoch << TAG_SLICE_BITS) | slice);
+    static const bool helpers = [] {
+        const char *e = getenv("FELICS_SPINE");
+        return !(e && strcmp(e, "single") == 0);
+    }();  // FELICS_SPINE=single: the one-wave walk for every chain (k_spine)
+    if (helpers)
+        FELICS_LAUNCH((k_spine2<ET>), dim3(nchains), dim3(256), s, sorted_e, block_state, chain_base, chain_len,
+                           nchains, tile_off, g.sort_tiles, t_end, chain_prog, block_tag,
+                           reinterpret_cast<uint2 *>(partial) + (uint64_t)(slice - 1) * nchains,
+                           (epoch << TAG_SLICE_BITS) | slice);
+    else
+        FELICS_LAUNCH((k_spine<ET>), dim3(nchains), dim3(64), s, sorted_e, block_state, chain_base, chain_len,
+                           nchains, tile_off, g.sort_tiles, t_end, chain_prog, block_tag,
+                           reinterpret_cast<uint2 *>(partial) + (uint64_t)(slice - 1) * nchains,
+                           (epoch << TAG_SLICE_BITS) | slice);
 }
 template void launch_spine<uint8_t>(hipStream_t, const uint8_t *, uint32_t *, const uint32_t *, const uint32_t *,
                                     const uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t,

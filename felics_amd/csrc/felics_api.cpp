@@ -11,6 +11,7 @@
 #include <thread>
 #include <type_traits>
 #include <string>
+#include <new>
 #include <vector>
 
 #include "../../include/felics.h"
@@ -21,9 +22,9 @@ using namespace felics;
 namespace {
 
 enum Stage { ST_PLANES = 0, ST_HIST, ST_OFFSETS, ST_SCATTER, ST_SPINE, ST_ASSIGN, ST_LENGTHS, ST_BITSCAN, ST_ZERO, ST_PACK,
-             ST_WIDE_KEYS, ST_WIDE_SORT, ST_WIDE_CHAINS, ST_STRIPE, ST_COUNT };
+             ST_WIDE_KEYS, ST_WIDE_SORT, ST_WIDE_CHAINS, ST_COUNT };
 const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "spine", "assign", "lengths", "bitscan", "zero", "pack",
-                                     "wide_keys", "wide_sort", "wide_chains", "stripe"};
+                                     "wide_keys", "wide_sort", "wide_chains"};
 static_assert(ST_COUNT <= FELICS_MAX_STAGES, "felics.h promises at most FELICS_MAX_STAGES stages");
 
 constexpr int SLICES = 12;              // at most; a submission uses lane.nslices of them
@@ -61,8 +62,6 @@ struct Lane {
     DevBuf planes, counts, chain_len, chain_base, chain_prog, scalars, sorted_e, pix_of, k_map, k_sorted, block_state, group_bits,
         tile_bits, tile_bitoff, plane_sums, image_bytes, image_off, partial, block_tag, status, edge_first, edge_last, pscratch;
     DevBuf wrecs[2], wtile_cnt, wmeta, whist, wdigtot, heads;  // 16-bit samples: event records (sort double buffer), tile counts, plane ranges, digit histograms, chain heads
-    DevBuf s_ctl, s_table, s_status, s_stamps;                     // fused tile kernel: control block, estimator tables, look-back words
-    bool ran_stripe = false;                             // the sub-batch in flight went through the fused tile kernel
     uint32_t epoch = 0;               // sub-batches this lane has run: block tags are (epoch, slice)
     // the submission in flight on this lane (felics_submit_batch_device .. felics_wait_batch)
     bool pending = false;
@@ -94,10 +93,6 @@ struct felics_ctx {
     // a launch and a hand-over per stage: few slices are faster there (measured: 12 -> 5.3, 6 -> 5.1, 3 -> 4.8 ms).
     int slices_blocking = 6;    // FELICS_SLICES
     int slices_queued = 4;      // FELICS_SLICES_QUEUED
-    bool stripe = false;        // FELICS_PIPELINE=stripe: 8-bit frames with fixed output slots go through the fused tile kernel
-                                // (felics_stripe.hip) instead of the multi-kernel pipeline.  Measured slower so far,
-                                // hence opt-in; a hand-off of that kernel that gives up moves the context back for good
-    uint32_t stripe_wgs = 256;  // workgroups of the persistent kernel: one per CU (its LDS fills a CU); FELICS_STRIPE_WGS
     // Where the k of the events comes from (FELICS_ASSIGN):
     //   gather (default): k_assign_serial replays every 64-event block once, one lane per block, and leaves k in chain
     //                     order (k_sorted); the single-pass pack gathers it through the runs of its tile (k_pack_g)
@@ -112,7 +107,6 @@ struct felics_ctx {
     bool pack_tickets = false;
     bool two_pass = false;      // FELICS_TWO_PASS=1, or a look-back of the single-pass pack gave up once: lengths + pack kernels
     bool test_timeout = false;  // FELICS_TEST_TIMEOUT=1: every wait for the GPU reports a time-out (tests of the failed state)
-    bool test_stripe_fail = false; // FELICS_TEST_STRIPE_FAIL=1: pretend the first fused-kernel submission gave up (tests)
     bool test_lookback = false; // FELICS_TEST_LOOKBACK_FAIL=1: pretend the first single-pass submission gave up (tests)
     bool poison = false;        // FELICS_POISON=1: overwrite the workspace before every sub-batch (tests)
     bool trace = false;         // FELICS_TRACE=1: synchronise and report after every stage (debugging)
@@ -481,112 +475,6 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     return FELICS_OK;
 }
 
-// The fused tile kernel (felics_stripe.hip): one persistent launch per sub-batch takes every tile from pixels to
-// packed bits inside LDS.  Needs fixed output slots (like the single-pass pack); same contract as run_lane
-// towards the caller: sizes and the error word land in the lane's pinned buffer, `sized` is recorded behind them.
-template <typename T>
-int run_stripe(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
-    const Geometry &g = l.g;
-    const uint32_t ntiles = (uint32_t)(((uint64_t)g.npix + StripeCfg<T>::TILE - 1) / StripeCfg<T>::TILE);
-    const size_t ntt = (size_t)g.nplanes * ntiles;
-    int rc;
-    if ((rc = reserve(ctx, l.s_ctl, (size_t)(STRIPE_CTL_DONE + g.nplanes) * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, l.s_table, (size_t)g.nplanes * NCTX * 24)) != 0) return rc;
-    if ((rc = reserve_zeroed(ctx, l.s_status, ntt * 8)) != 0) return rc;
-    if ((rc = reserve(ctx, l.tile_bits, ntt * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, l.tile_bitoff, ntt * 8)) != 0) return rc;
-    if ((rc = reserve(ctx, l.edge_first, ntt * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, l.edge_last, ntt * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, l.plane_sums, (size_t)g.nplanes * 16)) != 0) return rc;
-    if ((rc = reserve(ctx, l.image_bytes, (size_t)g.nimages * 8)) != 0) return rc;
-    if ((rc = reserve(ctx, l.image_off, (size_t)(g.nimages + 1) * 8)) != 0) return rc;
-    const size_t hs = (size_t)g.nimages * 2 + 1;
-    if (hs > l.h_sizes_cap) {
-        if (l.h_sizes) HIP_TRY(ctx, hipHostFree(l.h_sizes));
-        l.h_sizes = nullptr;
-        HIP_TRY(ctx, hipHostMalloc((void **)&l.h_sizes, hs * 8 + 64, hipHostMallocDefault));
-        l.h_sizes_cap = hs;
-    }
-    PackTarget target{d_out, slot_stride, nullptr, 0};
-    if (g.planes_per_image > 1) {
-        target.plane_slot = ((uint64_t)g.npix + g.npix / 4 + 64 + 15) & ~15ull;
-        if ((rc = reserve(ctx, l.pscratch, (size_t)(target.plane_slot * g.nimages * (g.planes_per_image - 1)))) != 0) return rc;
-        target.scratch = (uint8_t *)l.pscratch.p;
-    }
-    if (++l.epoch >= 0x03FFFFFFu) l.epoch = 1;
-    if ((l.epoch & 0x3FFFFu) == 0) HIP_TRY(ctx, hipMemset(l.s_status.p, 0, l.s_status.cap));  // look-back tags: 18 epoch bits
-    hipStream_t s = l.stream;
-    auto *plane_carry = (uint64_t *)l.plane_sums.p;
-    auto *plane_base = plane_carry + g.nplanes;
-    if (ctx->poison) {
-        DevBuf *bufs[] = {&l.tile_bits, &l.tile_bitoff, &l.edge_first, &l.edge_last, &l.pscratch};
-        for (DevBuf *b : bufs)
-            if (b->p) HIP_TRY(ctx, hipMemsetAsync(b->p, 0xA5, b->cap, s));
-    }
-    HIP_TRY(ctx, hipMemsetAsync(l.s_ctl.p, 0, (size_t)(STRIPE_CTL_DONE + g.nplanes) * 4, s));
-    HIP_TRY(ctx, hipMemsetAsync(l.s_table.p, 0, (size_t)g.nplanes * NCTX * 24, s));
-    HIP_TRY(ctx, hipMemsetAsync(plane_carry, 0, (size_t)g.nplanes * 16, s));
-    StripeArgs a;
-    a.planes = l.d_planes;
-    a.W = g.W;
-    a.H = g.H;
-    a.npix = g.npix;
-    a.nplanes = g.nplanes;
-    a.ntiles = ntiles;
-    a.ctl = (uint32_t *)l.s_ctl.p;
-    a.table = (uint64_t *)l.s_table.p;
-    a.status = (uint64_t *)l.s_status.p;
-    a.tile_bitoff = (uint64_t *)l.tile_bitoff.p;
-    a.tile_bits = (uint32_t *)l.tile_bits.p;
-    a.plane_carry = plane_carry;
-    a.edge_first = (uint32_t *)l.edge_first.p;
-    a.edge_last = (uint32_t *)l.edge_last.p;
-    a.po = PlaneOut{target.out, target.slot_stride, target.scratch, target.plane_slot, g.planes_per_image};
-    a.color = g.color;
-    a.depth = g.depth;
-    a.epoch = l.epoch;
-    a.stamps = nullptr;
-    if (const char *path = getenv("FELICS_STRIPE_STAMPS")) {  // debugging aid: phase stamps of every tile, dumped to a file
-        (void)path;
-        if ((rc = reserve(ctx, l.s_stamps, ntt * STRIPE_STAMPS * 8)) != 0) return rc;
-        HIP_TRY(ctx, hipMemsetAsync(l.s_stamps.p, 0, ntt * STRIPE_STAMPS * 8, s));
-        a.stamps = (uint64_t *)l.s_stamps.p;
-    }
-    {
-        StageTimer t(ctx, l, ST_STRIPE, s, true);
-        HIP_TRY(ctx, launch_stripe<T>(s, a, ctx->stripe_wgs));
-    }
-    {
-        StageTimer t(ctx, l, ST_ZERO, s);
-        launch_finish_sizes(s, plane_carry, plane_base, (uint64_t *)l.image_bytes.p, g);
-        launch_join_edges_tiles(s, (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p, (const uint32_t *)l.edge_first.p,
-                                (const uint32_t *)l.edge_last.p, target, g, ntiles);
-        launch_concat_planes(s, plane_base, plane_carry, target, g);
-    }
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(l.h_sizes, l.image_bytes.p, (size_t)g.nimages * 8, hipMemcpyDeviceToHost, s));
-    l.h_sizes[g.nimages] = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&l.h_sizes[g.nimages], (uint32_t *)l.s_ctl.p + STRIPE_CTL_ERROR, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipEventRecord(l.sized, s));
-    if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(l.span_end, s));
-    if (a.stamps) {
-        std::vector<uint64_t> h(ntt * STRIPE_STAMPS);
-        HIP_TRY(ctx, hipMemcpy(h.data(), a.stamps, ntt * STRIPE_STAMPS * 8, hipMemcpyDeviceToHost));
-        if (FILE *f = fopen(getenv("FELICS_STRIPE_STAMPS"), "wb")) {
-            const uint32_t hdr[4] = {g.nplanes, ntiles, STRIPE_STAMPS, 0};
-            fwrite(hdr, 4, 4, f);
-            fwrite(h.data(), 8, h.size(), f);
-            fclose(f);
-        }
-    }
-    return FELICS_OK;
-}
-
-template <typename T>
-bool stripe_fits(const felics_ctx *ctx, uint32_t w, uint64_t slot) {
-    return ctx->stripe && slot != 0 && stripe_lds_bytes<T>(w) <= STRIPE_LDS_LIMIT;
-}
-
 // 16-bit samples (T = u16 gray planes, i32 Y/Co/Cg planes): everything on the lane's main stream.
 //   keys -> stable sort by (plane, context) -> chain heads -> estimator replay per chain (k_map)
 //   -> lengths, bit scan, sizes -> pack (fixed slots) ; same contract as run_lane towards the caller.
@@ -720,8 +608,12 @@ size_t max_images_per_pass(uint64_t npix, uint32_t planes, int depth) {
     if (per_image == 0) return SIZE_MAX;
     if (const char *e = getenv("FELICS_TEST_PASS_IMAGES"))  // tests: several passes without a 100 GB batch
         return (size_t)std::max(1, atoi(e));
-    if (depth == FELICS_DEPTH_16)  // ~30 bytes of workspace per sample: keep a pass near 2^30 samples
-        return (size_t)std::max<uint64_t>(1, 0x40000000ull / per_image);
+    if (depth == FELICS_DEPTH_16) {
+        // ~30 bytes of workspace per sample: keep a pass near 2^30 samples -- and near 2^16 planes: the 16-bit front end scans
+        // tiles x planes counts in one workgroup and searches the plane table per sort tile (a batch of many tiny frames)
+        constexpr uint64_t WIDE_MAX_PLANES = 1u << 16;
+        return (size_t)std::max<uint64_t>(1, std::min<uint64_t>(0x40000000ull / per_image, WIDE_MAX_PLANES / planes));
+    }
     return (size_t)std::max<uint64_t>(1, 0xE0000000ull / (per_image + 64ull * planes * NCTX));
 }
 
@@ -753,10 +645,9 @@ int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const v
     l.d_planes = src;
     if (ctx->profiling)  // on the stream the sub-batch's first kernel runs on
         HIP_TRY(ctx, hipEventRecord(l.span_begin, wide || getenv("FELICS_SERIAL") ? l.stream : l.front));
-    l.ran_stripe = !wide && (planes == 3 ? stripe_fits<int16_t>(ctx, w, slot) : stripe_fits<uint8_t>(ctx, w, slot));
     if (planes == 3) {
         if ((rc = reserve(ctx, l.planes, (size_t)g.nplanes * npix * (wide ? 4 : 2) + STAGE_PAD)) != 0) return rc;
-        hipStream_t fs = wide || l.ran_stripe || getenv("FELICS_SERIAL") ? l.stream : l.front;
+        hipStream_t fs = wide || getenv("FELICS_SERIAL") ? l.stream : l.front;
         StageTimer t(ctx, l, ST_PLANES, fs, true);
         if (wide)
             launch_rgb16_to_planes(fs, (const uint16_t *)src, (int32_t *)l.planes.p, g.npix, g.nimages);
@@ -765,8 +656,6 @@ int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const v
         l.d_planes = l.planes.p;
     }
     if (wide) return planes == 3 ? run_wide<int32_t>(ctx, l, lane_out, slot) : run_wide<uint16_t>(ctx, l, lane_out, slot);
-    if (l.ran_stripe) ctx->stats.fused_submissions++;
-    if (l.ran_stripe) return planes == 3 ? run_stripe<int16_t>(ctx, l, lane_out, slot) : run_stripe<uint8_t>(ctx, l, lane_out, slot);
     return planes == 3 ? run_lane<int16_t, uint16_t>(ctx, l, lane_out, slot) : run_lane<uint8_t, uint8_t>(ctx, l, lane_out, slot);
 }
 
@@ -778,8 +667,7 @@ struct SlotOutcome {
 
 SlotOutcome read_sizes(felics_ctx *ctx, Lane &l, bool wide, uint64_t slot, uint64_t *offsets, uint64_t *lens) {
     SlotOutcome o;
-    if (!wide && ((l.h_sizes[l.g.nimages] & 1u) != 0 || (ctx->test_lookback && !ctx->two_pass && !l.ran_stripe))) o.lookback_failed = true;
-    if (l.ran_stripe && ctx->test_stripe_fail) o.lookback_failed = true;
+    if (!wide && ((l.h_sizes[l.g.nimages] & 1u) != 0 || (ctx->test_lookback && !ctx->two_pass))) o.lookback_failed = true;
     if (!wide && (l.h_sizes[l.g.nimages] & 2u) != 0) o.overflow = true;
     for (size_t i = 0; i < l.g.nimages; i++) {
         lens[l.first_image + i] = l.h_sizes[i];
@@ -900,15 +788,9 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
             // kernels holding the GPU, most likely): this context packs in two passes from now on.
             if ((rc = sync_lane(ctx, l)) != 0) return rc;
             ctx->stats.lookback_fallbacks++;
-            if (l.ran_stripe) {
-                ctx->stripe = false;
-                ctx->test_stripe_fail = false;
-                ctx->err = "a tile of the fused kernel gave up waiting for its predecessor: this context now uses the multi-kernel pipeline (slower)";
-            } else {
-                ctx->two_pass = true;
-                ctx->stats.two_pass = 1;
-                ctx->err = "a tile gave up waiting for its predecessors: this context now packs with the two-pass kernels (slower)";
-            }
+            ctx->two_pass = true;
+            ctx->stats.two_pass = 1;
+            ctx->err = "a tile gave up waiting for its predecessors: this context now packs with the two-pass kernels (slower)";
             continue;
         }
         if (!outcome.overflow) break;
@@ -955,14 +837,7 @@ int felics_ctx_create(int device, felics_ctx **out) {
         ctx->assign_mode = strcmp(e, "kernel") == 0 ? felics_ctx::ASSIGN_KERNEL : strcmp(e, "inpack") == 0 ? felics_ctx::ASSIGN_INPACK : felics_ctx::ASSIGN_GATHER;
     if (const char *e = getenv("FELICS_TICKETS")) ctx->pack_tickets = atoi(e) != 0;
     if (getenv("FELICS_OWN_TAILS")) ctx->pack_tickets = true;
-    ctx->test_stripe_fail = getenv("FELICS_TEST_STRIPE_FAIL") != nullptr;
     ctx->test_timeout = getenv("FELICS_TEST_TIMEOUT") != nullptr;
-    if (const char *e = getenv("FELICS_PIPELINE")) ctx->stripe = strcmp(e, "stripe") == 0;
-    {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->stripe_wgs = (uint32_t)cus;
-        if (const char *e = getenv("FELICS_STRIPE_WGS")) ctx->stripe_wgs = (uint32_t)std::max(1, atoi(e));
-    }
     if (const char *e = getenv("FELICS_SLICES")) ctx->slices_blocking = std::max(1, std::min(atoi(e), SLICES));
     if (const char *e = getenv("FELICS_SLICES_QUEUED")) ctx->slices_queued = std::max(1, std::min(atoi(e), SLICES));
     ctx->trace = getenv("FELICS_TRACE") != nullptr;
@@ -1029,8 +904,7 @@ void felics_ctx_destroy(felics_ctx *ctx) {
     for (Lane &l : ctx->lanes) {
         DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map, &l.k_sorted,
                           &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.plane_sums, &l.image_bytes, &l.image_off,
-                          &l.partial, &l.block_tag, &l.status, &l.edge_first, &l.edge_last, &l.pscratch, &l.wrecs[0], &l.wrecs[1], &l.wtile_cnt, &l.wmeta, &l.whist, &l.wdigtot, &l.heads,
-                          &l.s_ctl, &l.s_table, &l.s_status, &l.s_stamps};
+                          &l.partial, &l.block_tag, &l.status, &l.edge_first, &l.edge_last, &l.pscratch, &l.wrecs[0], &l.wrecs[1], &l.wtile_cnt, &l.wmeta, &l.whist, &l.wdigtot, &l.heads};
         for (DevBuf *b : bufs) release(*b);
         if (l.h_sizes) (void)hipHostFree(l.h_sizes);
         for (int i = 0; i < ST_COUNT; i++)
@@ -1151,15 +1025,9 @@ int felics_wait_batch(felics_ctx *ctx, int ticket, uint64_t *offsets, uint64_t *
     if ((rc = sync_lane(ctx, l)) != 0) return rc;
     if (o.lookback_failed) {
         ctx->stats.lookback_fallbacks++;
-        if (l.ran_stripe) {
-            ctx->stripe = false;
-            ctx->test_stripe_fail = false;
-            ctx->err = "a tile of the fused kernel gave up waiting for its predecessor: this context now uses the multi-kernel pipeline (slower)";
-        } else {
-            ctx->two_pass = true;
-            ctx->stats.two_pass = 1;
-            ctx->err = "a tile gave up waiting for its predecessors: this context now packs with the two-pass kernels (slower)";
-        }
+        ctx->two_pass = true;
+        ctx->stats.two_pass = 1;
+        ctx->err = "a tile gave up waiting for its predecessors: this context now packs with the two-pass kernels (slower)";
     } else {
         ctx->stats.slot_overflows++;
     }
@@ -1237,34 +1105,60 @@ int felics_decompress_batch_device(felics_ctx *ctx, size_t n, const void *d_stre
     uint8_t h0[FELICS_HEADER_BYTES] = {0};
     const size_t hl = (size_t)std::min<uint64_t>(lens[0], FELICS_HEADER_BYTES);
     if (hl) HIP_TRY(ctx, hipMemcpy(h0, (const uint8_t *)d_streams + offsets[0], hl, hipMemcpyDeviceToHost));
+    // every stream gets a status on every path out of here (felics.h): a call that ends before the streams are decoded
+    // reports its own error for all of them
+    auto fail_all = [&](int code) {
+        for (size_t i = 0; i < n; i++) status[i] = code;
+        return code;
+    };
     felics_header hdr;
     int rc = felics_read_header(h0, hl, &hdr);
-    if (rc) {
-        status[0] = rc;
-        return rc;
-    }
+    if (rc) return fail_all(rc);  // stream 0 names the shape: without it nothing is decoded
     if (hdr_out) *hdr_out = hdr;
     const uint32_t planes = hdr.color_type == FELICS_COLOR_RGB ? 3 : 1;
     const size_t bps = hdr.pixel_depth == FELICS_DEPTH_16 ? 2 : 1;
     const uint64_t npix = (uint64_t)hdr.width * hdr.height;
-    if (npix > 0xFFFFFFFFull) return FELICS_E_INVALID_DIMENSIONS;
+    if (npix > 0xFFFFFFFFull) return fail_all(FELICS_E_INVALID_DIMENSIONS);
     const uint64_t frame_bytes = npix * planes * bps;
-    if (frame_bytes * n > d_pixels_cap) return FELICS_E_BUFFER_TOO_SMALL;
-    if (frame_bytes && !d_pixels) return FELICS_E_INVALID_ARGUMENT;
-    if (bps == 2 || decode8_lds_bytes(hdr.width, hdr.color_type) > STRIPE_LDS_LIMIT) {
+    if (frame_bytes * n > d_pixels_cap) return fail_all(FELICS_E_BUFFER_TOO_SMALL);
+    if (frame_bytes && !d_pixels) return fail_all(FELICS_E_INVALID_ARGUMENT);
+    // a stream of this shape is never longer than this: a caller's length beyond it is not a stream (and not a size to allocate)
+    const uint64_t max_len = felics_max_compressed_size(hdr.width, hdr.height, hdr.color_type, hdr.pixel_depth);
+    if (bps == 2 || decode8_lds_bytes(hdr.width, hdr.color_type) > DECODE_LDS_LIMIT) {
         // host decoder, stream by stream
-        std::vector<uint8_t> sbuf, pbuf((size_t)frame_bytes);
+        std::vector<uint8_t> sbuf, pbuf;
+        try {
+            pbuf.resize((size_t)frame_bytes);
+            sbuf.reserve((size_t)std::min<uint64_t>(max_len, 1ull << 32));
+        } catch (const std::bad_alloc &) {
+            return fail_all(FELICS_E_IO);
+        }
         int first_rc = FELICS_OK;
         for (size_t i = 0; i < n; i++) {
-            sbuf.resize((size_t)lens[i]);
-            if (lens[i]) HIP_TRY(ctx, hipMemcpy(sbuf.data(), (const uint8_t *)d_streams + offsets[i], (size_t)lens[i], hipMemcpyDeviceToHost));
+            if (lens[i] > max_len) {  // (checked before anything is sized by it)
+                status[i] = FELICS_E_INVALID_VALUE;
+                if (!first_rc) first_rc = FELICS_E_INVALID_VALUE;
+                continue;
+            }
+            try {
+                sbuf.resize((size_t)lens[i]);
+            } catch (const std::bad_alloc &) {
+                for (size_t k = i; k < n; k++) status[k] = FELICS_E_IO;
+                return first_rc ? first_rc : FELICS_E_IO;
+            }
+            if (lens[i] && hipMemcpy(sbuf.data(), (const uint8_t *)d_streams + offsets[i], (size_t)lens[i], hipMemcpyDeviceToHost) != hipSuccess) {
+                for (size_t k = i; k < n; k++) status[k] = FELICS_E_HIP;
+                return hip_fail(ctx, hipGetLastError(), "copying a stream to the host decoder");
+            }
             felics_header hi;
             int r = felics_read_header(sbuf.data(), sbuf.size(), &hi);
             if (!r && (hi.width != hdr.width || hi.height != hdr.height || hi.color_type != hdr.color_type || hi.pixel_depth != hdr.pixel_depth))
                 r = FELICS_E_INVALID_DIMENSIONS;
             if (!r) r = felics_decompress(sbuf.data(), sbuf.size(), pbuf.data(), pbuf.size(), nullptr);
-            if (!r && frame_bytes)
-                HIP_TRY(ctx, hipMemcpy((uint8_t *)d_pixels + i * frame_bytes, pbuf.data(), (size_t)frame_bytes, hipMemcpyHostToDevice));
+            if (!r && frame_bytes && hipMemcpy((uint8_t *)d_pixels + i * frame_bytes, pbuf.data(), (size_t)frame_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+                for (size_t k = i; k < n; k++) status[k] = FELICS_E_HIP;
+                return hip_fail(ctx, hipGetLastError(), "copying decoded pixels to the device");
+            }
             status[i] = r;
             if (r && !first_rc) first_rc = r;
         }
@@ -1272,15 +1166,16 @@ int felics_decompress_batch_device(felics_ctx *ctx, size_t n, const void *d_stre
     }
     // offsets | lens | status on the device
     const size_t meta = n * 8 * 2 + n * 4;
-    if ((rc = reserve(ctx, ctx->dec_meta, meta)) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->dec_meta, meta)) != 0) return fail_all(rc);
     uint64_t *d_off = (uint64_t *)ctx->dec_meta.p, *d_len = d_off + n;
     int *d_status = (int *)(d_len + n);
     int16_t *d_planes = nullptr;
     if (planes == 3) {
-        if ((rc = reserve(ctx, ctx->dec_planes, (size_t)(npix * 3 * 2 * n) + 64)) != 0) return rc;
+        if ((rc = reserve(ctx, ctx->dec_planes, (size_t)(npix * 3 * 2 * n) + 64)) != 0) return fail_all(rc);
         d_planes = (int16_t *)ctx->dec_planes.p;
     }
     hipStream_t s = l.stream;
+    for (size_t i = 0; i < n; i++) status[i] = FELICS_E_HIP;  // until the kernel's own word arrives
     HIP_TRY(ctx, hipMemcpyAsync(d_off, offsets, n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_len, lens, n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(d_status, 0xFF, n * 4, s));

@@ -1,5 +1,5 @@
 // felics_codes.h -- device code shared by the kernel translation units that build and pack codes
-// (felics_kernels.hip: multi-kernel pipeline; felics_stripe.hip: the fused tile kernel):
+// (felics_kernels.hip):
 // Rice lengths and block sums of the estimator, the phased-in / Rice code builders, the MSB-first
 // bit writers and the look-back status words.
 #pragma once

@@ -47,6 +47,9 @@ struct ScalarBits {
     uint32_t navail;       // valid bits in acc
     uint64_t end_bit;      // bits from `al` to the end of the stream
 
+    // (whole aligned dwords: the first and the last one may hold up to three bytes that are not the stream's -- never
+    // interpreted: `skew` bytes are dropped at the start, end_bit bounds the end -- and an aligned word that holds a stream
+    // byte cannot leave the page that byte is in)
     __device__ __forceinline__ uint32_t fetch(uint64_t first) const {
         const uint64_t i = first + lane_id();
         return i < total_dw ? __builtin_bswap32(al[i]) : 0u;
@@ -312,7 +315,7 @@ hipError_t launch_decode8(hipStream_t s, const uint8_t *streams, const uint64_t 
     const uint32_t lds = decode8_lds_bytes(W, color);
     if (lds > 64u * 1024u) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode8),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)STRIPE_LDS_LIMIT);
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)DECODE_LDS_LIMIT);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_decode8, dim3(n), dim3(64), lds, s, streams, offsets, lens, W, H, color, pixels, planes, status);

@@ -203,46 +203,11 @@ struct PlaneOut {
 };
 
 
-// ---- the fused tile kernel (felics_stripe.hip): 8-bit frames, one persistent kernel per submission.
-// A workgroup takes a tile of consecutive pixels of one plane through classification, event partition,
-// estimator replay, code construction and packing without leaving LDS; tiles of a plane hand the estimator's
-// table (global memory, 512 rows of six counters per plane) to each other in order.
-constexpr uint32_t STRIPE_THREADS = 1024;
-constexpr uint32_t STRIPE_LDS_LIMIT = 160u * 1024u;  // LDS of one CU (MI355X_MICROARCH.md)
-template <typename T> struct StripeCfg;
-template <> struct StripeCfg<uint8_t> {  // gray planes
-    using ET = uint8_t;
-    static constexpr uint32_t TILE = 16384, PPT = 16;
-};
-template <> struct StripeCfg<int16_t> {  // Y / Co / Cg planes
-    using ET = uint16_t;
-    static constexpr uint32_t TILE = 8192, PPT = 8;
-};
-// control block (u32 words, zeroed before every launch): ticket counter, error bits (1 = a wait gave up,
-// 2 = an RGB plane outgrew its scratch slot), then done[plane] = tiles of the plane whose estimator rows are out
-constexpr uint32_t STRIPE_STAMPS = 16 + 16 * 4;  // per ticket: 16 of thread 0, 4 of every wave
-constexpr uint32_t STRIPE_CTL_TICKET = 0, STRIPE_CTL_ERROR = 1, STRIPE_CTL_DONE = 16;
-struct StripeArgs {
-    const void *planes;
-    uint32_t W, H, npix, nplanes, ntiles;  // ntiles = ceil(npix / TILE)
-    uint32_t *ctl;                          // STRIPE_CTL_DONE + nplanes words
-    uint64_t *table;                        // nplanes * NCTX * 3 words, zeroed before every launch
-    uint64_t *status;                       // nplanes * ntiles look-back words (zeroed once; epoch tags)
-    uint64_t *tile_bitoff;
-    uint32_t *tile_bits;
-    uint64_t *plane_carry;
-    uint32_t *edge_first, *edge_last;
-    PlaneOut po;
-    uint32_t color, depth, epoch;
-    uint64_t *stamps;  // debugging aid (FELICS_STRIPE_STAMPS): STRIPE_STAMPS wall-clock stamps per ticket, or nullptr
-};
-template <typename T> uint32_t stripe_lds_bytes(uint32_t W);
-// at most max_workgroups workgroups (the tiles are handed out by a ticket counter)
-template <typename T> hipError_t launch_stripe(hipStream_t s, const StripeArgs &a, uint32_t max_workgroups);
-// join_edges / concat_planes for a given tile count (the stripe kernel's tiles are larger than the pack kernels')
+// join_edges for a given tile count
 void launch_join_edges_tiles(hipStream_t s, const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint32_t *edge_first,
                              const uint32_t *edge_last, const PackTarget &to, const Geometry &g, uint32_t ntiles);
 
+constexpr uint32_t DECODE_LDS_LIMIT = 160u * 1024u;  // LDS of one CU (MI355X_MICROARCH.md): what a decoder workgroup may ask for
 // ---- GPU decoder for 8-bit streams (felics_gpudecode.hip): one wave per stream.  status[i] = FELICS_OK or an error
 // code; gray pixels go straight to `pixels`, RGB through int16 planes (image i at i * 3 * npix) + a conversion kernel.
 uint32_t decode8_lds_bytes(uint32_t W, uint32_t color);

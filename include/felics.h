@@ -138,7 +138,11 @@ int felics_decompress_with_header(const uint8_t *in, size_t len, const felics_he
  * error).  *hdr (optional) receives the header all streams must share; it is read from stream 0.
  * Replaces n calls of `decompress_image` (compression.rs:420-441).  The format is bit-serial per stream (and the
  * planes of an RGB image share one bit stream), so the only parallelism is across streams: one wave per stream
- * for 8-bit data.  16-bit streams (a 7.9 MB estimator table per plane) are decoded by the host decoder and copied. */
+ * for 8-bit data.  16-bit streams (a 7.9 MB estimator table per plane) are decoded by the host decoder and copied.
+ * status[] is written for all n streams on every return (a call that ends before decoding -- bad header of stream 0, buffer too
+ * small, a HIP error -- puts its own code in every entry).  The kernel loads a stream as whole ALIGNED 32-bit words: it may
+ * touch up to three bytes on either side of a stream, always inside an aligned word that also holds a byte of the stream,
+ * hence never outside the page the stream lies in; those bytes are never interpreted. */
 int felics_decompress_batch_device(felics_ctx *ctx, size_t n, const void *d_streams, const uint64_t *offsets,
                                    const uint64_t *lens, void *d_pixels, size_t d_pixels_cap, felics_header *hdr,
                                    int *status);
@@ -152,7 +156,7 @@ const char *felics_last_error(const felics_ctx *ctx);
  * holding the GPU for a second -- moves the context to the two-pass kernels for good; felics_last_error says so.) */
 typedef struct felics_stats {
     uint64_t submissions;        /* sub-batches queued so far */
-    uint64_t fused_submissions;  /* ... of which through the fused tile kernel (8-bit frames with fixed output slots) */
+    uint64_t fused_submissions;  /* reserved, always 0 (round 2's opt-in fused tile kernel was measured slower and removed) */
     uint64_t slot_overflows;     /* batches redone with exact placement: a stream outgrew its fixed slot */
     uint64_t lookback_fallbacks; /* batches redone because a tile gave up waiting for its predecessors */
     int two_pass;                /* 1: the context packs with the two-pass kernels from now on (slower) */

@@ -32,8 +32,11 @@ COPY = [
     "grayscale/8bit/6.3.09.tiff", "grayscale/8bit/5.1.09.tiff", "grayscale/8bit/6.1.01.tiff",
     "grayscale/16bit/aerial.tiff", "grayscale/16bit/man.tiff",
     "rgb/8bit/house.tiff", "rgb/8bit/tree.tiff", "rgb/8bit/lena_color_256.tif",
+    # little-endian multi-strip files (the readers' strip logic; lena_color_256.tif above is one too): RGB in 74 strips without a
+    # PlanarConfiguration tag, 16-bit gray of odd size (1081 x 1081) in 3 strips
+    "rgb/8bit/mandril_color.tif", "grayscale/16bit/heightmap.tiff",
 ]
-DOC_SIZE_PINS = {"house.tiff": 105741, "tree.tiff": 122246, "lena_color_256.tif": 110707}
+DOC_SIZE_PINS = {"house.tiff": 105741, "tree.tiff": 122246, "lena_color_256.tif": 110707, "mandril_color.tif": 617524}
 
 
 def main():

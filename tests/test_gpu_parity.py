@@ -298,89 +298,6 @@ def test_pack_variants(oracle):
             e.close()
 
 
-def test_fused_tile_kernel(oracle):
-    """FELICS_PIPELINE=stripe: 8-bit frames through the single persistent kernel of felics_stripe.hip (tiles handed
-    out by ticket, estimator table passed from tile to tile).  Same bytes as the oracle on the reference's shapes,
-    odd geometry, extreme content, RGB, batches, 4K frames, two submissions in flight, and -- with a forced
-    hand-off failure -- the fall back to the multi-kernel pipeline."""
-    import felics_amd
-    import torch
-    from felics_amd import synth
-
-    rng = np.random.default_rng(41)
-    os.environ["FELICS_PIPELINE"] = "stripe"
-    os.environ["FELICS_POISON"] = "1"
-    try:
-        e = felics_amd.Encoder(0)
-    finally:
-        del os.environ["FELICS_PIPELINE"], os.environ["FELICS_POISON"]
-    try:
-        n0 = e.stats()["fused_submissions"]
-        for w, h in DIMS + [(17, 300), (4097, 3), (3, 3000), (1, 5000), (5000, 1), (5000, 2), (255, 257), (8000, 9)]:
-            _check(e, oracle, rng.integers(0, 256, size=(h, w), dtype=np.uint8), "stripe gray noise")
-            _check(e, oracle, (np.add.outer(np.arange(h), np.arange(w)) // 3 % 256).astype(np.uint8), "stripe smooth")
-            _check(e, oracle, rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8), "stripe rgb noise")
-        for w in range(1, 20, 3):
-            for h in range(1, 20, 3):
-                _check(e, oracle, rng.integers(0, 256, size=(h, w), dtype=np.uint8))
-                _check(e, oracle, rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8))
-        flat = np.full((96, 257), 7, np.uint8)
-        spikes = flat.copy()
-        spikes[rng.integers(0, 96, 200), rng.integers(0, 257, 200)] = 255
-        checker = ((np.indices((96, 257)).sum(0) & 1) * 255).astype(np.uint8)
-        for img in (flat, spikes, checker):
-            _check(e, oracle, img, "stripe extreme")
-            _check(e, oracle, np.stack([img, img[::-1], 255 - img], axis=-1).copy(), "stripe extreme rgb")
-        assert e.stats()["fused_submissions"] > n0 + 100
-        for kind in ("S1", "S2", "S3"):
-            _check(e, oracle, synth.gray8(3840, 2160, 1, kind), "stripe 4K " + kind)
-        _check(e, oracle, synth.rgb8(3840, 2160, 2), "stripe 4K rgb")
-        frames = [synth.gray8(1920, 1080, f, "S1") for f in range(12)] + [synth.gray8(1920, 1080, 3, "S2")]
-        assert e.compress_batch(frames) == [oracle.compress(f) for f in frames]
-        rgb = [synth.rgb8(640, 360, f) for f in range(5)]
-        assert e.compress_batch(rgb) == [oracle.compress(f) for f in rgb]
-        # two submissions in flight
-        batches = [[synth.gray8(1280, 720, 10 * b + f, "S1") for f in range(6)] for b in range(4)]
-        d_in = [torch.from_numpy(np.stack(fr)).cuda() for fr in batches]
-        caps = [int(sum(f.nbytes for f in fr) * 1.25) + 4096 for fr in batches]
-        d_out = [torch.zeros(c, dtype=torch.uint8, device="cuda") for c in caps]
-        torch.cuda.synchronize()
-        subs = []
-        for b in range(4):
-            if len(subs) == 2:
-                bb, sub = subs.pop(0)
-                offs, lens = e.wait_batch(sub)
-                host = d_out[bb].cpu().numpy()
-                for i, f in enumerate(batches[bb]):
-                    assert host[int(offs[i]): int(offs[i] + lens[i])].tobytes() == oracle.compress(f), (bb, i)
-            subs.append((b, e.submit_batch_device(d_in[b].data_ptr(), 6, 1280, 720, 0, 0, d_out[b].data_ptr(), caps[b])))
-        for bb, sub in subs:
-            offs, lens = e.wait_batch(sub)
-            host = d_out[bb].cpu().numpy()
-            for i, f in enumerate(batches[bb]):
-                assert host[int(offs[i]): int(offs[i] + lens[i])].tobytes() == oracle.compress(f), (bb, i)
-        assert e.stats()["lookback_fallbacks"] == 0
-    finally:
-        e.close()
-    # a hand-off that gives up: the batch is redone by the multi-kernel pipeline and the context stays there
-    os.environ["FELICS_PIPELINE"] = "stripe"
-    os.environ["FELICS_TEST_STRIPE_FAIL"] = "1"
-    try:
-        e = felics_amd.Encoder(0)
-    finally:
-        del os.environ["FELICS_PIPELINE"], os.environ["FELICS_TEST_STRIPE_FAIL"]
-    try:
-        frames = [synth.gray8(800, 600, f, "S1") for f in range(4)]
-        want = [oracle.compress(f) for f in frames]
-        assert e.compress_batch(frames) == want
-        st = e.stats()
-        assert st["lookback_fallbacks"] == 1 and st["fused_submissions"] == 1
-        assert e.compress_batch(frames) == want
-        assert e.stats()["fused_submissions"] == 1
-    finally:
-        e.close()
-
-
 def test_random_shapes_and_contents(enc, oracle):
     """A few seconds of random geometry (1 pixel wide to 5000), content (noise, ramps, flat with full-scale
     spikes, constant), sample type and batch size, every stream compared with the oracle."""
@@ -672,3 +589,118 @@ def test_slot_overflow_falls_back_to_exact_placement(enc, oracle):
     host = d_out.cpu().numpy()
     for i in range(3):
         assert host[int(offs[i]): int(offs[i] + lens[i])].tobytes() == want[i], i
+
+
+def test_teardown_after_every_lane_was_used(oracle):
+    """Destroying a context whose lanes have all run (they share the tail stream), with shared and with private tail
+    streams and for every lane count, and destroying a failed context.  Round 2's records hold an abort inside
+    felics_ctx_destroy (gpurun_out/r2b/t2.log): lane 0's loop iteration destroyed the shared tail stream and lane 1's
+    iteration then synchronised the same handle; DESIGN.md 5.1.  Run once: a teardown that aborts takes the process."""
+    import felics_amd
+    import torch
+    from felics_amd import synth
+
+    frames = [synth.gray8(960, 540, f, "S1") for f in range(4)]
+    want = [oracle.compress(f) for f in frames]
+    d_in = torch.from_numpy(np.stack(frames)).cuda()
+    for env in ({}, {"FELICS_LANES": "1"}, {"FELICS_LANES": "3"}, {"FELICS_LANES": "4"}, {"FELICS_OWN_TAILS": "1"},
+                {"FELICS_LANES": "4", "FELICS_OWN_TAILS": "1"}):
+        os.environ.update(env)
+        try:
+            e = felics_amd.Encoder(0)
+            depth_q = int(felics_amd.api.lib().felics_lane_count())
+        finally:
+            for k in env:
+                del os.environ[k]
+        outs = [torch.zeros(4 * 960 * 540 * 2, dtype=torch.uint8, device="cuda") for _ in range(depth_q)]
+        subs = [e.submit_batch_device(d_in.data_ptr(), 4, 960, 540, 0, 0, o.data_ptr(), o.numel()) for o in outs]  # every lane
+        for sub, o in zip(subs, outs):
+            offs, lens = e.wait_batch(sub)
+            host = o.cpu().numpy()
+            assert [host[int(a): int(a + n)].tobytes() for a, n in zip(offs, lens)] == want, env
+        last = e.submit_batch_device(d_in.data_ptr(), 4, 960, 540, 0, 0, outs[0].data_ptr(), outs[0].numel())
+        e.wait_batch(last)
+        e.close()  # the teardown under test
+    # a context that failed while a lane was busy: nothing of it is touched, the process goes on
+    os.environ["FELICS_TEST_TIMEOUT"] = "1"
+    try:
+        e = felics_amd.Encoder(0)
+    finally:
+        del os.environ["FELICS_TEST_TIMEOUT"]
+    out = torch.zeros(4 * 960 * 540 * 2, dtype=torch.uint8, device="cuda")
+    sub = e.submit_batch_device(d_in.data_ptr(), 4, 960, 540, 0, 0, out.data_ptr(), out.numel())
+    with pytest.raises(felics_amd.FelicsError):
+        e.wait_batch(sub)
+    torch.cuda.synchronize()
+    e.close()
+    with felics_amd.Encoder(0) as e2:
+        assert e2.compress_batch(frames) == want
+
+
+def _golden_images():
+    from PIL import Image
+
+    out = {}
+    for p in sorted(glob.glob(os.path.join(GOLDEN, "*.tif")) + glob.glob(os.path.join(GOLDEN, "*.tiff"))):
+        out[os.path.basename(p)] = np.array(Image.open(p))
+    return out
+
+
+def _mosaic(tiles, rows, cols):
+    """rows x cols mosaic of same-shape tiles, every other one mirrored (so that the seams are not all alike)."""
+    out = []
+    for r in range(rows):
+        row = []
+        for c in range(cols):
+            t = tiles[(r * cols + c) % len(tiles)]
+            if (r + c) % 2:
+                t = t[:, ::-1]
+            if r % 2:
+                t = t[::-1]
+            row.append(t)
+        out.append(np.concatenate(row, axis=1))
+    return np.ascontiguousarray(np.concatenate(out, axis=0))
+
+
+def test_natural_image_mosaics(enc, oracle):
+    """The reference's integration test round-trips its whole image suite (tests/compress.rs:73-103); the GPU box only has
+    the eight 256 x 256 golden files, so natural content larger than 16 tiles is built from them: 2048 x 2048 mosaics
+    (gray8, gray16, RGB8; every other tile mirrored), one 1500 x 1100 mosaic with ragged geometry, and a 64-frame batch of
+    shifted 1024 x 768 crops -- all byte-compared with the oracle."""
+    imgs = _golden_images()
+    gray8 = [a for a in imgs.values() if a.ndim == 2 and a.dtype == np.uint8 and a.shape == (256, 256)]
+    gray16 = [a for a in imgs.values() if a.ndim == 2 and a.dtype == np.uint16 and a.shape == (256, 256)]
+    rgb8 = [a for a in imgs.values() if a.ndim == 3 and a.dtype == np.uint8 and a.shape[:2] == (256, 256)]
+    assert gray8 and rgb8, sorted(imgs)
+    big8 = _mosaic(gray8, 8, 8)
+    _check(enc, oracle, big8, "gray8 mosaic")
+    _check(enc, oracle, _mosaic(rgb8, 8, 8), "rgb8 mosaic")
+    if gray16:
+        _check(enc, oracle, _mosaic(gray16, 8, 8), "gray16 mosaic")
+    else:  # no 16-bit golden of that size: the 8-bit content scaled, with natural-looking low bits
+        wide = (big8.astype(np.uint16) << 8) | np.roll(big8, 7, axis=1).astype(np.uint16)
+        _check(enc, oracle, wide, "gray16 mosaic (scaled gray8 content)")
+    _check(enc, oracle, np.ascontiguousarray(_mosaic(gray8, 6, 6)[:1100, :1500]), "ragged gray8 mosaic")
+    crops = [np.ascontiguousarray(big8[7 * i: 7 * i + 768, 13 * i: 13 * i + 1024]) for i in range(64)]
+    got = enc.compress_batch(crops)
+    for i in (0, 1, 31, 63):
+        assert got[i] == oracle.compress(crops[i]), i
+    import felics_amd
+
+    for i in range(64):
+        assert (felics_amd.decompress_image(io.BytesIO(got[i])) == crops[i]).all(), i
+
+
+def test_many_tiny_sixteen_bit_frames(enc, oracle):
+    """A batch of 70 000 tiny 16-bit frames: the 16-bit path takes at most 2^16 planes per pass (its front end scans tiles x
+    planes counts in one workgroup), so this batch goes through two passes; a sample is compared with the oracle and decoded back."""
+    import felics_amd
+
+    rng = np.random.default_rng(11)
+    base = [rng.integers(0, 65536, size=(5, 7), dtype=np.uint16) for _ in range(257)]
+    frames = [base[i % 257] for i in range(70000)]
+    got = enc.compress_batch(frames)
+    want = [oracle.compress(f) for f in base]
+    assert all(got[i] == want[i % 257] for i in range(70000))
+    for i in range(0, 70000, 4999):
+        assert (felics_amd.decompress_image(io.BytesIO(got[i])) == frames[i]).all(), i

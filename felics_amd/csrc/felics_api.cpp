@@ -65,6 +65,9 @@ struct Lane {
     uint32_t epoch = 0;               // sub-batches this lane has run: block tags are (epoch, slice)
     // the submission in flight on this lane (felics_submit_batch_device .. felics_wait_batch)
     bool pending = false;
+    bool tail_pending = false;        // queued on the shared stream: the front and the spine are queued, k + pack are not yet (run_lane)
+    bool m_two_pass = false;          // the context's pack / assign mode when this sub-batch's front was queued (its tail uses the same)
+    int m_assign = 0;
     bool finished = false;            // it took the synchronous path: results are in r_off / r_len / r_rc
     size_t p_n = 0;
     const void *p_pixels = nullptr;
@@ -86,6 +89,16 @@ struct Lane {
 
 struct felics_ctx {
     int device = -1;
+    // FELICS_SCHED=shared: queued submissions (felics_submit_batch_device) put all their GPU-filling kernels on ONE stream shared
+    // by the lanes, in an order the host chooses: front of batch i + 1 (histogram, offsets, scatter), then k + pack of batch i
+    // -- the tail of a batch is queued when the next batch is submitted (or when the batch is waited for).  Every one of these
+    // kernels is issue-bound, so two of them side by side only halve each other (the stages of a step sum to 2.6 ms of
+    // launches run alone and to 5.5 ms side by side); in this order each runs with the GPU to itself, only the spine of batch
+    // i + 1 underneath.  Built and measured in round 3: the kernels do run at their stand-alone speed, and the step is no
+    // shorter (see sched_shared) -- the default stays per-lane streams, everything side by side.
+    hipStream_t tstream = nullptr;
+    bool sched_shared = false;  // (measured round 3: 3.28-3.36 ms per step shared against 3.09-3.14 with per-lane streams: the spine of batch i + 1 -- its
+                                // helper waves sum every block of every chain -- takes a fifth of the issue slots from whatever runs beside it either way)
     int next_lane = 0;          // lane of the next felics_submit_batch_device
     int nlanes = DEFAULT_LANES; // lanes in use (FELICS_LANES)
     // Slices per sub-batch.  A blocking call has the GPU to itself: more slices let assign / pack follow the
@@ -174,6 +187,7 @@ int sync_lane(felics_ctx *ctx, Lane &l) {
     if (l.stream) HIP_TRY(ctx, hipStreamSynchronize(l.stream));
     if (l.kstream) HIP_TRY(ctx, hipStreamSynchronize(l.kstream));
     if (l.tail) HIP_TRY(ctx, hipStreamSynchronize(l.tail));
+    if (ctx->tstream) HIP_TRY(ctx, hipStreamSynchronize(ctx->tstream));
     return FELICS_OK;
 }
 
@@ -269,13 +283,18 @@ void header_bytes(uint8_t *o, uint32_t w, uint32_t h, int color, int depth) {
 //                  1 and 2 needs the size of the planes before them).
 // The stream sizes are copied to the lane's pinned buffer and `sized` is recorded behind them.
 // slot_stride == 0: no packing here (the caller places the streams exactly once it has the sizes).
+enum Phase { PH_ALL = 0, PH_FRONT = 1, PH_TAIL = 2 };  // run_lane: everything / up to the spine launches / k + pack + sizes
+
 template <typename T, typename ET>
-int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
+int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride, Phase phase, bool shared) {
     const Geometry &g = l.g;
     const int ns = l.nslices;
     const size_t nsamples = (size_t)g.nplanes * g.npix;
     const size_t slots = (size_t)max_event_slots(g);
-    int rc;
+    int rc = 0;
+    if (phase != PH_TAIL) {
+    l.m_two_pass = ctx->two_pass;
+    l.m_assign = ctx->assign_mode;
     if ((rc = reserve(ctx, l.counts, (size_t)g.nplanes * g.sort_tiles * g.nctx * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.chain_len, (size_t)g.nplanes * g.nctx * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.chain_base, (size_t)g.nplanes * g.nctx * 4)) != 0) return rc;
@@ -305,8 +324,10 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         l.h_sizes_cap = hs;
     }
 
+    }
     hipStream_t s = l.stream, f = l.front, ks = l.kstream, tl = l.tail;
     if (getenv("FELICS_SERIAL")) f = ks = tl = s;  // debugging aid: one stream, same order of launches
+    if (shared) f = ks = tl = ctx->tstream;        // (see felics_ctx::tstream)
     const T *d_planes = (const T *)l.d_planes;
     auto *counts = (uint32_t *)l.counts.p;
     auto *chain_len = (uint32_t *)l.chain_len.p;
@@ -315,19 +336,21 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     auto *plane_carry = (uint64_t *)l.plane_sums.p;
     auto *plane_base = plane_carry + g.nplanes;
     // tags of other sub-batches never match this epoch (the lane's tags are cleared when the counter wraps)
-    if (++l.epoch >= 0x03FFFFFFu) {
-        HIP_TRY(ctx, hipMemset(l.block_tag.p, 0, l.block_tag.cap));
-        l.epoch = 1;
+    if (phase != PH_TAIL) {
+        if (++l.epoch >= 0x03FFFFFFu) {
+            HIP_TRY(ctx, hipMemset(l.block_tag.p, 0, l.block_tag.cap));
+            l.epoch = 1;
+        }
+        if ((l.epoch & 0x3FFFFu) == 0) HIP_TRY(ctx, hipMemset(l.status.p, 0, l.status.cap));  // look-back tags: 18 epoch bits
     }
     const uint32_t epoch = l.epoch;
-    if ((epoch & 0x3FFFFu) == 0) HIP_TRY(ctx, hipMemset(l.status.p, 0, l.status.cap));  // look-back tags: 18 epoch bits
     // Fixed slots: code lengths, tile offsets and packing in one kernel per slice (one such kernel at a
     // time: the tiles of two of them waiting for each other's queued predecessors could hold all workgroup
     // slots, so the lanes share the tail stream).  It puts planes 1, 2 of an RGB image into scratch slots of
     // their own and moves them behind plane 0 at the end.
-    const bool fused = slot_stride != 0 && !ctx->two_pass;
-    const bool ink = fused && ctx->assign_mode == felics_ctx::ASSIGN_INPACK;  // k inside the pack kernel: the k stream has nothing to do
-    const bool gather = fused && ctx->assign_mode == felics_ctx::ASSIGN_GATHER;  // k in chain order (k stream), gathered by the pack kernel
+    const bool fused = slot_stride != 0 && !l.m_two_pass;
+    const bool ink = fused && l.m_assign == felics_ctx::ASSIGN_INPACK;  // k inside the pack kernel: the k stream has nothing to do
+    const bool gather = fused && l.m_assign == felics_ctx::ASSIGN_GATHER;  // k in chain order (k stream), gathered by the pack kernel
     const bool rel = ink || gather;  // the pack kernel knows its tile: pix_of holds 16-bit offsets into the sort tile
     // Two-pass kernels: gray frames pack slice by slice; RGB packs after the last slice (the offset of planes
     // 1 and 2 in their stream needs the size of the planes before them).
@@ -341,6 +364,12 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     uint32_t *d_error = (uint32_t *)l.scalars.p + 8;  // look-back watchdog of the single-pass pack
     uint32_t *d_tickets = (uint32_t *)l.scalars.p + 16;  // one per pack launch of this sub-batch: tiles are handed out in order
 
+    uint32_t bounds[SLICES + 1], pbounds[SLICES + 1];  // slice boundaries in sort tiles / pack tiles
+    for (int q = 0; q <= ns; q++) {
+        bounds[q] = (uint32_t)((uint64_t)g.sort_tiles * q / ns);
+        pbounds[q] = q == ns ? g.pack_tiles : std::min<uint32_t>(g.pack_tiles, bounds[q] * (SORT_TILE / PACK_TILE));
+    }
+    if (phase != PH_TAIL) {
     // ---- front stream
     if (ctx->poison) {  // FELICS_POISON: every intermediate buffer starts as garbage, as on a fresh context
         DevBuf *bufs[] = {&l.counts, &l.chain_len, &l.chain_base, &l.sorted_e, &l.pix_of, &l.k_map, &l.k_sorted, &l.block_state,
@@ -358,11 +387,6 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         launch_zero_padding<ET>(f, (ET *)l.sorted_e.p, rel ? nullptr : (uint32_t *)l.pix_of.p, chain_base, chain_len, g);
         HIP_TRY(ctx, hipMemsetAsync(chain_prog, 0, (size_t)g.nplanes * g.nctx * 32, f));
         HIP_TRY(ctx, hipMemsetAsync(l.partial.p, 0, (size_t)ns * g.nplanes * g.nctx * 8, f));
-    }
-    uint32_t bounds[SLICES + 1], pbounds[SLICES + 1];  // slice boundaries in sort tiles / pack tiles
-    for (int q = 0; q <= ns; q++) {
-        bounds[q] = (uint32_t)((uint64_t)g.sort_tiles * q / ns);
-        pbounds[q] = q == ns ? g.pack_tiles : std::min<uint32_t>(g.pack_tiles, bounds[q] * (SORT_TILE / PACK_TILE));
     }
     for (int q = 0; q < ns; q++) {
         if (bounds[q + 1] != bounds[q]) {
@@ -382,6 +406,11 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
                              (uint32_t)q + 1, g);
         }
         HIP_TRY(ctx, hipEventRecord(l.spine_done[q], s));
+    }
+    }
+    if (phase == PH_FRONT) {
+        HIP_TRY(ctx, hipGetLastError());
+        return FELICS_OK;
     }
     // ---- k stream: behind every spine launch, k of the events it published
     for (int q = 0; q < ns && !ink; q++) {
@@ -620,7 +649,10 @@ size_t max_images_per_pass(uint64_t npix, uint32_t planes, int depth) {
 // Queues one sub-batch (cnt frames starting at frame `first` of d_pixels) on a lane: geometry, colour
 // transform, and everything run_lane / run_wide enqueue.  Returns without waiting.
 int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const void *d_pixels, uint32_t w, uint32_t h,
-                     int color, int depth, uint8_t *lane_out, uint64_t slot, int nslices) {
+                     int color, int depth, uint8_t *lane_out, uint64_t slot, int nslices, Phase phase = PH_ALL, bool shared = false) {
+    if (phase == PH_TAIL)  // the geometry is the lane's (launch_sub_batch ... PH_FRONT set it)
+        return l.g.planes_per_image == 3 ? run_lane<int16_t, uint16_t>(ctx, l, lane_out, slot, PH_TAIL, shared)
+                                         : run_lane<uint8_t, uint8_t>(ctx, l, lane_out, slot, PH_TAIL, shared);
     l.nslices = std::max(1, std::min(nslices, SLICES));
     ctx->stats.submissions++;
     const uint32_t planes = color == FELICS_COLOR_RGB ? 3 : 1;
@@ -644,10 +676,10 @@ int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const v
     const uint8_t *src = (const uint8_t *)d_pixels + first * frame_bytes;
     l.d_planes = src;
     if (ctx->profiling)  // on the stream the sub-batch's first kernel runs on
-        HIP_TRY(ctx, hipEventRecord(l.span_begin, wide || getenv("FELICS_SERIAL") ? l.stream : l.front));
+        HIP_TRY(ctx, hipEventRecord(l.span_begin, wide || getenv("FELICS_SERIAL") ? l.stream : shared ? ctx->tstream : l.front));
     if (planes == 3) {
         if ((rc = reserve(ctx, l.planes, (size_t)g.nplanes * npix * (wide ? 4 : 2) + STAGE_PAD)) != 0) return rc;
-        hipStream_t fs = wide || getenv("FELICS_SERIAL") ? l.stream : l.front;
+        hipStream_t fs = wide || getenv("FELICS_SERIAL") ? l.stream : shared ? ctx->tstream : l.front;
         StageTimer t(ctx, l, ST_PLANES, fs, true);
         if (wide)
             launch_rgb16_to_planes(fs, (const uint16_t *)src, (int32_t *)l.planes.p, g.npix, g.nimages);
@@ -656,7 +688,7 @@ int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const v
         l.d_planes = l.planes.p;
     }
     if (wide) return planes == 3 ? run_wide<int32_t>(ctx, l, lane_out, slot) : run_wide<uint16_t>(ctx, l, lane_out, slot);
-    return planes == 3 ? run_lane<int16_t, uint16_t>(ctx, l, lane_out, slot) : run_lane<uint8_t, uint8_t>(ctx, l, lane_out, slot);
+    return planes == 3 ? run_lane<int16_t, uint16_t>(ctx, l, lane_out, slot, phase, shared) : run_lane<uint8_t, uint8_t>(ctx, l, lane_out, slot, phase, shared);
 }
 
 // What the sizes that came back say about a sub-batch packed into fixed slots.
@@ -802,6 +834,26 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
     return FELICS_OK;
 }
 
+// Queues deferred tails (k + pack + sizes) on the shared stream, oldest submission first.  The lanes are taken in turn, so
+// the oldest submission is on the lane the next submission will take (next_lane); `last` is the lane of the newest
+// submission whose tail is wanted: the one before the submission just queued (felics_submit_batch_device), or the one
+// being waited for (felics_wait_batch) -- a newer submission's tail stays deferred, behind the front of its successor.
+int flush_tails(felics_ctx *ctx, int first, int last) {
+    for (int li = first;; li = (li + 1) % ctx->nlanes) {
+        Lane &o = ctx->lanes[li];
+        if (o.tail_pending) {
+            o.tail_pending = false;
+            const int rc = launch_sub_batch(ctx, o, 0, o.p_n, o.p_pixels, o.p_w, o.p_h, o.p_color, o.p_depth, o.p_out, o.p_slot, 0, PH_TAIL, true);
+            if (rc) {
+                (void)sync_lane(ctx, o);
+                return rc;
+            }
+        }
+        if (li == last) break;
+    }
+    return FELICS_OK;
+}
+
 bool any_pending(const felics_ctx *ctx) {
     for (const Lane &l : ctx->lanes)
         if (l.pending) return true;
@@ -855,6 +907,8 @@ int felics_ctx_create(int device, felics_ctx **out) {
         if (strcmp(e, "frontfirst") == 0) prio_spine = prio_front = prio_high, prio_tail = prio_low;
         if (strcmp(e, "tailonly") == 0) prio_spine = prio_front = prio_low, prio_tail = prio_high;
     }
+    if (const char *e = getenv("FELICS_SCHED")) ctx->sched_shared = strcmp(e, "shared") == 0;
+    ok = ok && hipStreamCreateWithPriority(&ctx->tstream, hipStreamNonBlocking, prio_front) == hipSuccess;
     for (int li = 0; li < ctx->nlanes; li++) {
         Lane &l = ctx->lanes[li];
         ok = ok && hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio_spine) == hipSuccess;
@@ -901,6 +955,7 @@ void felics_ctx_destroy(felics_ctx *ctx) {
     }
     for (Lane &l : ctx->lanes)
         if (l.tail) (void)hipStreamSynchronize(l.tail);
+    if (ctx->tstream) (void)hipStreamSynchronize(ctx->tstream);
     for (Lane &l : ctx->lanes) {
         DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map, &l.k_sorted,
                           &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.plane_sums, &l.image_bytes, &l.image_off,
@@ -924,6 +979,7 @@ void felics_ctx_destroy(felics_ctx *ctx) {
         if (l.stream) (void)hipStreamDestroy(l.stream);
         if (l.tail && (&l == &ctx->lanes[0] || l.tail != ctx->lanes[0].tail)) (void)hipStreamDestroy(l.tail);
     }
+    if (ctx->tstream) (void)hipStreamDestroy(ctx->tstream);
     release(ctx->in);
     release(ctx->out);
     release(ctx->dec_meta);
@@ -985,10 +1041,14 @@ int felics_submit_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels, 
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         for (int i = 0; i < ST_COUNT; i++) l.ev_used[i] = 0;
         l.p_slot = slot;
-        if ((rc = launch_sub_batch(ctx, l, 0, n, d_pixels, w, h, color, depth, l.p_out, slot, ctx->slices_queued)) != 0) {
+        const bool defer = ctx->sched_shared && depth != FELICS_DEPTH_16;  // (the 16-bit path runs on one stream of its own as a whole)
+        if ((rc = launch_sub_batch(ctx, l, 0, n, d_pixels, w, h, color, depth, l.p_out, slot, ctx->slices_queued, defer ? PH_FRONT : PH_ALL, defer)) != 0) {
             (void)sync_lane(ctx, l);
             return rc;
         }
+        l.tail_pending = defer;
+        // behind this batch's front: the tails (k + pack) of the batches submitted before it (lanes L + 1 .. L - 1, oldest first)
+        if (ctx->nlanes > 1 && (rc = flush_tails(ctx, (L + 1) % ctx->nlanes, (L + ctx->nlanes - 1) % ctx->nlanes)) != 0) return rc;
     }
     l.pending = true;
     *ticket = L;
@@ -1002,6 +1062,9 @@ int felics_wait_batch(felics_ctx *ctx, int ticket, uint64_t *offsets, uint64_t *
     Lane &l = ctx->lanes[ticket];
     if (!l.pending) return FELICS_E_INVALID_ARGUMENT;
     if (!l.finished) {
+        // this batch's tail, if no later submission has queued it yet (and any older one's: callers may wait out of order)
+        int frc = flush_tails(ctx, ctx->next_lane, ticket);
+        if (frc) return frc;
         // the lane stays marked busy until its kernels are known to have finished: after a timeout nothing may
         // reuse or free its workspace
         const int wrc = wait_event(ctx, l.sized, "stream sizes");

@@ -670,7 +670,7 @@ extern "C" __attribute__((visibility("default"))) int felics_debug_spine_stamps(
 #define SCOUNT(i)
 #endif
 
-constexpr uint32_t SP_BATCH = 16;   // blocks per hand-over
+constexpr uint32_t SP_BATCH = 8;    // blocks per hand-over
 constexpr uint32_t SP_HELPERS = 3;
 constexpr uint32_t SP_SMALL = 24;   // blocks
 

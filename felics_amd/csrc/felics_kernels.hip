@@ -1213,47 +1213,55 @@ __device__ __forceinline__ void stage_pixels(TileLDS<T> &t, const T *__restrict_
     const int64_t fa = (int64_t)tile_first - STAGE_LEAD, fb = (int64_t)tile_first - W;
     const bool ala = ((reinterpret_cast<uintptr_t>(pl) + (uint64_t)fa * sizeof(T)) & 15u) == 0;
     const bool alb = ((reinterpret_cast<uintptr_t>(pl) + (uint64_t)fb * sizeof(T)) & 15u) == 0;
-    uint4 va[KA], vb[KB];
-    bool wa[KA], wb[KB];
     // what a chunk that is not loaded this way reads instead: the 16 aligned bytes the plane starts in (the planes of a
     // batch lie in one allocation, so these exist)
     const uint4 *safe = reinterpret_cast<const uint4 *>(pl - (reinterpret_cast<uintptr_t>(pl) & 15u) / sizeof(T));
-#pragma unroll
-    for (uint32_t k = 0; k < KA; k++) {
-        const uint32_t c = threadIdx.x + k * PACK_THREADS;
-        const int64_t g0 = fa + (int64_t)c * EPC;
-        wa[k] = c < NA && ala && g0 >= 0 && g0 + EPC <= (int64_t)npix;
-        va[k] = *(wa[k] ? reinterpret_cast<const uint4 *>(pl + g0) : safe);  // (no branch: a branch would be a wait per load)
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < KB; k++) {
-        const uint32_t c = threadIdx.x + k * PACK_THREADS;
-        const int64_t g0 = fb + (int64_t)c * EPC;
-        wb[k] = c < NB && alb && g0 >= 0 && g0 + EPC <= (int64_t)npix;
-        vb[k] = *(wb[k] ? reinterpret_cast<const uint4 *>(pl + g0) : safe);
-    }
     auto slowly = [&](T *lds, int64_t first, uint32_t c) {
         for (uint32_t e = 0; e < EPC; e++) {
             const int64_t gi = first + (int64_t)c * EPC + e;
             if (gi >= 0 && gi < (int64_t)npix) lds[c * EPC + e] = pl[gi];
         }
     };
-    // (every load is stored, the unwanted ones into a dump slot: a load that is only used under a condition is moved
-    // under that condition by the compiler, and then waited for there, one by one)
+    // The whole rounds of both spans (every thread one chunk of each per round: one round for byte samples, two for 16-bit
+    // ones), without a branch (a branch would be a wait per load; every load is stored, the unwanted ones into a dump slot:
+    // a load that is only used under a condition is moved under that condition by the compiler, and then waited for there).
+    constexpr uint32_t FA = NA / PACK_THREADS, FB = NB / PACK_THREADS;
+    static_assert(FA == FB && KA <= FA + 1 && KB <= FB + 1, "whole rounds, then at most one partial round");
+    uint4 va[FA], vb[FB];
+    bool wa[FA], wb[FB];
+#pragma unroll
+    for (uint32_t k = 0; k < FA; k++) {
+        const uint32_t c = threadIdx.x + k * PACK_THREADS;
+        const int64_t ga = fa + (int64_t)c * EPC, gb = fb + (int64_t)c * EPC;
+        wa[k] = ala && ga >= 0 && ga + EPC <= (int64_t)npix;
+        wb[k] = alb && gb >= 0 && gb + EPC <= (int64_t)npix;
+        va[k] = *(wa[k] ? reinterpret_cast<const uint4 *>(pl + ga) : safe);
+        vb[k] = *(wb[k] ? reinterpret_cast<const uint4 *>(pl + gb) : safe);
+    }
     uint4 *dump = reinterpret_cast<uint4 *>(t.dump);
 #pragma unroll
-    for (uint32_t k = 0; k < KA; k++) *(wa[k] ? reinterpret_cast<uint4 *>(t.cur) + (threadIdx.x + k * PACK_THREADS) : dump) = va[k];
-#pragma unroll
-    for (uint32_t k = 0; k < KB; k++) *(wb[k] ? reinterpret_cast<uint4 *>(t.up) + (threadIdx.x + k * PACK_THREADS) : dump) = vb[k];
-#pragma unroll
-    for (uint32_t k = 0; k < KA; k++) {
+    for (uint32_t k = 0; k < FA; k++) {
         const uint32_t c = threadIdx.x + k * PACK_THREADS;
-        if (!wa[k] && c < NA) slowly(t.cur, fa, c);
+        *(wa[k] ? reinterpret_cast<uint4 *>(t.cur) + c : dump) = va[k];
+        *(wb[k] ? reinterpret_cast<uint4 *>(t.up) + c : dump) = vb[k];
     }
 #pragma unroll
-    for (uint32_t k = 0; k < KB; k++) {
+    for (uint32_t k = 0; k < FA; k++) {
         const uint32_t c = threadIdx.x + k * PACK_THREADS;
-        if (!wb[k] && c < NB) slowly(t.up, fb, c);
+        if (!wa[k]) slowly(t.cur, fa, c);
+        if (!wb[k]) slowly(t.up, fb, c);
+    }
+    // the chunks beyond (the elements in front of / behind the tile: one or two chunks of each span): a few threads
+    const uint32_t c1 = threadIdx.x + FA * PACK_THREADS;
+    if (c1 < NA) {
+        const int64_t g1 = fa + (int64_t)c1 * EPC;
+        if (ala && g1 >= 0 && g1 + EPC <= (int64_t)npix) reinterpret_cast<uint4 *>(t.cur)[c1] = *reinterpret_cast<const uint4 *>(pl + g1);
+        else slowly(t.cur, fa, c1);
+    }
+    if (c1 < NB) {
+        const int64_t g1 = fb + (int64_t)c1 * EPC;
+        if (alb && g1 >= 0 && g1 + EPC <= (int64_t)npix) reinterpret_cast<uint4 *>(t.up)[c1] = *reinterpret_cast<const uint4 *>(pl + g1);
+        else slowly(t.up, fb, c1);
     }
 }
 
@@ -1937,58 +1945,61 @@ __device__ __forceinline__ void pack_tile_fused(TileLDS<T> &tl, const uint8_t *k
     const bool first_shared = (tile_lo & 31u) != 0, last_shared = (tile_hi & 31u) != 0;
     const bool overflowed = bits > LOCAL_WORDS * 32u;
 
-    // ---- phase 2: window by window
-    for (uint64_t w0 = first_word; w0 <= last_word; w0 += FUSED_WIN_WORDS) {
-        if (w0 != first_word) {  // (the first window was cleared above)
+    // ---- phase 2: window by window.  Word indices are kept relative to the tile's first word (32 bits: a tile has fewer
+    // than 2^22 bits); the common case is one window and a string inside the thread's LOCAL_WORDS words, whose shifted words
+    // go out in a fixed number of predicated steps (no loop, no branch per word).
+    const uint32_t nwords = (uint32_t)(last_word - first_word) + 1u;                       // words the tile touches
+    const uint32_t my_rel = (uint32_t)(tile_lo & 31u) + woff + inc - bits;                  // this thread's first bit, from the tile's first word
+    uint32_t *out_rel = out_words + first_word;                                              // (only dereferenced below limit_words)
+    const uint32_t limit_rel = limit_words > first_word ? (uint32_t)std::min<uint64_t>(limit_words - first_word, 0xFFFFFFFFull) : 0u;
+    for (uint32_t wb = 0; wb < nwords; wb += FUSED_WIN_WORDS) {
+        if (wb != 0) {  // (the first window was cleared above)
             __syncthreads();
             for (uint32_t j = threadIdx.x; j < FUSED_WIN_WORDS; j += PACK_THREADS) win[j] = 0;
             __syncthreads();
         }
-        if (bits != 0 && ((my_lo + bits - 1) >> 5) >= w0 && (my_lo >> 5) < w0 + FUSED_WIN_WORDS) {
-            if (!overflowed) {
-                const uint32_t shift = (uint32_t)(my_lo & 31u), nsrc = (bits + 31u) >> 5;
-                const uint64_t dw0 = my_lo >> 5;
-                uint32_t prev = 0;
-                for (uint32_t sidx = 0; sidx <= nsrc; sidx++) {
-                    const uint32_t cur = sidx < nsrc ? lbuf[sidx * PACK_THREADS + threadIdx.x] : 0u;
-                    const uint32_t v = shift ? (prev << (32u - shift)) | (cur >> shift) : cur;
-                    prev = cur;
-                    const uint64_t rel = dw0 + sidx - w0;
-                    if (v != 0 && rel < FUSED_WIN_WORDS) atomicOr(&win[rel], v);
-                }
-            } else {  // more bits than the private buffer holds: build the codes again, straight into the window
-                LaneBits bw;
-                bw.win = win;
-                bw.win_words = FUSED_WIN_WORDS;
-                bw.win_word0 = w0;
-                bw.begin(my_lo);
-                if (has_header) {
-                    bw.put(0x464C4353u, 32);
-                    bw.put((color << 8) | depth, 16);
-                    bw.put(W, 32);
-                    bw.put(H, 32);
-                }
-                walk_group(tl, kq, pl, first, end, W,
-                           [&](uint32_t, uint32_t rv) {
-                               bw.put(rv, 32);
-                               if (npix == 1) bw.put(0u, 32);
-                           },
-                           [&](const PixelClass &pc, uint32_t k) { put_pixel(bw, pc, k); });
-                bw.finish();
+        if (!overflowed) {
+            const uint32_t shift = my_rel & 31u, nsrc = (bits + 31u) >> 5;
+            const uint32_t rel0 = (my_rel >> 5) - wb;  // (wraps below the window: the unsigned compare drops it)
+            uint32_t prev = 0;
+#pragma unroll
+            for (uint32_t sidx = 0; sidx <= LOCAL_WORDS; sidx++) {
+                const uint32_t cur = sidx < nsrc ? lbuf[sidx * PACK_THREADS + threadIdx.x] : 0u;
+                const uint32_t v = (uint32_t)((((uint64_t)prev << 32) | cur) >> shift);
+                prev = cur;
+                if (v != 0 && rel0 + sidx < FUSED_WIN_WORDS) atomicOr(&win[rel0 + sidx], v);
             }
+        } else if (((my_rel + bits - 1) >> 5) >= wb && (my_rel >> 5) < wb + FUSED_WIN_WORDS) {
+            // more bits than the private buffer holds: build the codes again, straight into the window
+            LaneBits bw;
+            bw.win = win;
+            bw.win_words = FUSED_WIN_WORDS;
+            bw.win_word0 = first_word + wb;
+            bw.begin(my_lo);
+            if (has_header) {
+                bw.put(0x464C4353u, 32);
+                bw.put((color << 8) | depth, 16);
+                bw.put(W, 32);
+                bw.put(H, 32);
+            }
+            walk_group(tl, kq, pl, first, end, W,
+                       [&](uint32_t, uint32_t rv) {
+                           bw.put(rv, 32);
+                           if (npix == 1) bw.put(0u, 32);
+                       },
+                       [&](const PixelClass &pc, uint32_t k) { put_pixel(bw, pc, k); });
+            bw.finish();
         }
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < FUSED_WIN_WORDS; j += PACK_THREADS) {
-            const uint64_t aw = w0 + j;
-            if (aw > last_word) break;
+#pragma unroll
+        for (uint32_t u = 0; u < FUSED_WIN_WORDS / PACK_THREADS; u++) {
+            const uint32_t j = threadIdx.x + u * PACK_THREADS, r = wb + j;  // word r of the tile
             const uint32_t v = win[j];
-            if (aw == first_word && first_shared) {
-                edge_first[(uint64_t)plane * ntiles + tile] = v;  // merged with the previous tile's last word later
-            } else if (aw == last_word && last_shared) {
-                edge_last[(uint64_t)plane * ntiles + tile] = v;
-            } else if (aw < limit_words) {
-                out_words[aw] = __builtin_bswap32(v);
-            }
+            // the tile's first and last word may be shared with its neighbours: those go to the edge arrays (k_join_edges)
+            const bool is_first = r == 0 && first_shared, is_last = r == nwords - 1u && last_shared;
+            if (r < nwords && !is_first && !is_last && r < limit_rel) out_rel[r] = __builtin_bswap32(v);
+            if (is_first) edge_first[(uint64_t)plane * ntiles + tile] = v;  // merged with the previous tile's last word later
+            else if (is_last && r < nwords) edge_last[(uint64_t)plane * ntiles + tile] = v;
         }
     }
     PSTAMP(8);

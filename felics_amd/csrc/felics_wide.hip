@@ -374,14 +374,14 @@ __global__ __launch_bounds__(256) void k_wide_chains(const uint64_t *__restrict_
         uint32_t S[WIDE_NK];
 #pragma unroll
         for (int k = 0; k < WIDE_NK; k++) S[k] = 0;
-        uint64_t cur = j + lane < plane_end ? recs[j + lane] : ~0ull;
+        uint64_t cur = j + lane < plane_end ? __builtin_nontemporal_load(&recs[j + lane]) : ~0ull;  // (streamed once: kept out of the caches, which the k bytes need)
         for (;;) {
             const bool valid = j + lane < plane_end && rec_ctx(cur) == ctx;
             const uint64_t vm = __ballot(valid);  // a prefix of the lanes
             const uint32_t nvalid = (uint32_t)__popcll(vm);
             if (nvalid == 0) break;
             const uint64_t mine = cur;
-            if (nvalid == 64u) cur = j + 64u + lane < plane_end ? recs[j + 64u + lane] : ~0ull;  // next block, in flight
+            if (nvalid == 64u) cur = j + 64u + lane < plane_end ? __builtin_nontemporal_load(&recs[j + 64u + lane]) : ~0ull;  // next block, in flight
             const uint32_t pix = rec_pix(mine);
             const uint32_t e = valid ? rec_e(mine) : 0u;
             // One set of prefix sums per block; a halving at lane f turns the counters into ((S + P(f)) >> 1) - P(f), to which the

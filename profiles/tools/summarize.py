@@ -39,7 +39,7 @@ if rows:
 
 steps_in_command = 2  # the profiled command runs one checked and one timed step
 counters = collections.defaultdict(lambda: collections.defaultdict(float))
-for kind in ("fetch", "write", "sq"):
+for kind in ("fetch", "write", "sq", "sq2"):
     for f in glob.glob(out + "/" + kind + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
@@ -50,7 +50,8 @@ for kind in ("fetch", "write", "sq"):
 X2 = {"k_spine": "x2: uint4 loads of the event blocks", "k_pack_fused": "x2: uint4 staging of pixels and k",
       "k_pack": "x2: uint4 staging", "k_lengths": "x2: uint4 staging", "k_concat_planes": "x1",
       "k_pack_k": "raw + input bytes: the uint4 staging of the pixels (once the input size) is its only wide load; events are read as bytes / dwords",
-      "k_stripe": "x2: uint4 staging of the tile"}
+      "k_pack_g": "raw + input bytes: the uint4 staging of the pixels (once the input size) is its only wide load; k, offsets and the run table are read as bytes / words / dwords",
+      "k_assign_serial": "x2: uint4 loads of the events and the block states"}
 res = {}
 total = 0
 valu_total = 0
@@ -63,7 +64,9 @@ for k, c in sorted(counters.items()):
         fetch_c = fetch + 64 * 3840 * 2160  # the workload's input, read once with 16-byte loads and counted at half
     e = {"fetch_bytes_raw": int(fetch), "fetch_rule": rule, "fetch_bytes_per_step": int(fetch_c), "write_bytes_per_step": int(write),
          "hbm_bytes_per_step": int(fetch_c + write)}
-    for name in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+    for name in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_LDS",
+                 "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM",
+                 "SQ_INSTS_BRANCH"):
         if name in c:
             e[name] = int(c[name])
     res[k] = e
@@ -76,7 +79,7 @@ if counters:
     res["_valu_wave_insts_per_step"] = int(valu_total)
     res["_source_sha256"] = fbuild.source_hash()
     res["_workload"] = "64 synthetic S1 3840x2160 gray8 frames per step (bench.py default), blocking call"
-    res["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in three separate counter-only passes of `bench.py --steps 1 --warmup 0 "
+    res["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (two groups) in four separate counter-only passes of `bench.py --steps 1 --warmup 0 "
                     "--synchronous ...` (one checked + one timed step: sums halved).  bench.py uses this file only while "
                     "_source_sha256 equals the hash of the native sources it runs (felics_amd/build.py: source_hash).")
     json.dump(res, open(out + "/traffic.json", "w"), indent=1)

@@ -3,7 +3,7 @@ f=glob.glob(sys.argv[1]+'/*/*kernel_trace.csv')[0]
 rows=[r for r in csv.DictReader(open(f)) if 'felics' in r['Kernel_Name']]
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 nl=int(sys.argv[2]) if len(sys.argv)>2 else 2
-idx=[i for i,r in enumerate(rows) if 'k_hist' in r['Kernel_Name']]
+idx=[i for i,r in enumerate(rows) if 'k_hist' in r['Kernel_Name']] or [i for i,r in enumerate(rows) if 'k_wide_count' in r['Kernel_Name']]
 start=idx[-nl]
 last=rows[start:]
 base=int(last[0]['Start_Timestamp'])

@@ -371,6 +371,10 @@ def main():
                 return {"kernel": "k_pack_fused", "inpack": "k_pack_k"}.get(os.environ.get("FELICS_ASSIGN", ""), "k_pack_g")
             if stage == "offsets":
                 return "k_tile_offsets"
+            if stage == "spine":
+                return "k_spine" if os.environ.get("FELICS_SPINE") == "single" else "k_spine2"
+            if stage == "zero":
+                return "k_finish_sizes+k_join_edges"
             if stage == "assign" and os.environ.get("FELICS_ASSIGN", "") not in ("kernel", "inpack") and not args.depth16:
                 return "k_assign_serial"
             return "k_" + stage

@@ -374,14 +374,22 @@ __global__ __launch_bounds__(256) void k_wide_chains(const uint64_t *__restrict_
         uint32_t S[WIDE_NK];
 #pragma unroll
         for (int k = 0; k < WIDE_NK; k++) S[k] = 0;
-        uint64_t cur = j + lane < plane_end ? __builtin_nontemporal_load(&recs[j + lane]) : ~0ull;  // (streamed once: kept out of the caches, which the k bytes need)
+        // Records are streamed two blocks ahead with unconditional loads (index clamped to the plane's last record) and k
+        // leaves with an unconditional store (lanes without an event write a spare byte behind the planes): no branch around
+        // a memory operation, so the wait for a block's records is a counted one that leaves the younger operations -- the
+        // two prefetches and the scattered k bytes of the block before -- in flight.  (With the loads and the store under
+        // conditions the compiler waited for everything, the k bytes included, once per block: 16 us per 64 events.)
+        const uint32_t last_rec = plane_end - 1u;
+        uint8_t *const spare = k_map + (uint64_t)nplanes * npix;  // (the buffer is STAGE_PAD bytes longer than the planes)
+        uint64_t cur = __builtin_nontemporal_load(&recs[min(j + lane, last_rec)]);
+        uint64_t nx1 = __builtin_nontemporal_load(&recs[min(j + 64u + lane, last_rec)]);
         for (;;) {
             const bool valid = j + lane < plane_end && rec_ctx(cur) == ctx;
             const uint64_t vm = __ballot(valid);  // a prefix of the lanes
             const uint32_t nvalid = (uint32_t)__popcll(vm);
             if (nvalid == 0) break;
             const uint64_t mine = cur;
-            if (nvalid == 64u) cur = j + 64u + lane < plane_end ? __builtin_nontemporal_load(&recs[j + 64u + lane]) : ~0ull;  // next block, in flight
+            const uint64_t nx2 = __builtin_nontemporal_load(&recs[min(j + 128u + lane, last_rec)]);  // two blocks ahead
             const uint32_t pix = rec_pix(mine);
             const uint32_t e = valid ? rec_e(mine) : 0u;
             // One set of prefix sums per block; a halving at lane f turns the counters into ((S + P(f)) >> 1) - P(f), to which the
@@ -426,9 +434,11 @@ __global__ __launch_bounds__(256) void k_wide_chains(const uint64_t *__restrict_
                     break;
                 }
             }
-            if (valid) kp[pix] = (uint8_t)my_k;
+            *(valid ? kp + pix : spare) = (uint8_t)my_k;
             if (nvalid < 64u) break;
             j += 64u;
+            cur = nx1;
+            nx1 = nx2;
         }
     }
 }

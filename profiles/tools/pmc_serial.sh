@@ -26,7 +26,7 @@ cd /tmp
 for p in $passes; do
   echo "[pmc] $p: ${G[$p]}"
   rm -rf "$O/pmc_$p"
-  timeout -k 10 300 rocprofv3 --pmc ${G[$p]} --output-format csv -d "$O/pmc_$p" -- python3 "$R/bench.py" --steps 1 --warmup 0 --synchronous --no-blocking-extra --no-side-configs --no-decode-leg --cpu-seconds 0 --check-frames 1 > "$O/pmc_$p.log" 2>&1 || { tail -5 "$O/pmc_$p.log"; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc ${G[$p]} --output-format csv -d "$O/pmc_$p" -- python3 "$R/bench.py" --steps 1 --warmup 0 --synchronous --no-blocking-extra --no-side-configs --no-decode-leg --cpu-seconds 0 --check-frames 1 $PMC_BENCH_ARGS > "$O/pmc_$p.log" 2>&1 || { tail -5 "$O/pmc_$p.log"; exit 1; }
   python3 "$R/profiles/tools/pmc_agg.py" "$O/pmc_$p" 2 > "$O/pmc_$p.txt"
   rm -rf "$O/pmc_$p"
   cat "$O/pmc_$p.txt"

@@ -2199,7 +2199,10 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 5))) __global__ __launch
     uint8_t *kq = tl.kq;
     uint32_t x, plane;
 #ifdef FELICS_PACK_STAMPS
-    if (threadIdx.x == 0) fl.t_last = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 12; i++) fl.t_acc[i] = 0;
+        fl.t_last = __builtin_amdgcn_s_memtime();
+    }
 #endif
     take_ticket(fa, fl, x, plane);
     PSTAMP(0);

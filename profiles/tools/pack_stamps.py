@@ -1,4 +1,5 @@
-"""Where a pack_k workgroup's time goes, phase by phase (s_memtime stamps of thread 0, summed per tile).
+"""Where a pack workgroup's time goes, phase by phase (s_memtime stamps of thread 0, summed per tile): k_pack_g by default,
+k_pack_k with FELICS_ASSIGN=inpack.
 
 Needs a library built with the stamps compiled in (they are not in the product build):
     make -C felics_amd/csrc lib OUT=../../scratch/pstamps CXXFLAGS="-O3 -std=c++17 -fPIC -DFELICS_PACK_STAMPS"
@@ -31,10 +32,14 @@ dt = (time.time() - t) / R
 lib.felics_debug_pack_stamps(buf, 0)
 a = np.array(list(buf), dtype=np.float64).reshape(256, 16); v = list(a.sum(0))
 cnt = v[15]
-names = ["ticket", "items: expansion + barrier", "own assign loop", "wait other waves", "stage pixels", "phase 1 (codes)", "sync", "look-back + sync", "phase 2 (window, stores)", "items: loads + staging", "items: scan + barrier"]
+if os.environ.get("FELICS_ASSIGN") == "inpack":
+    names = ["ticket", "items: expansion + barrier", "own assign loop", "wait other waves", "stage pixels", "phase 1 (codes)", "sync", "look-back + sync", "phase 2 (window, stores)", "items: loads + staging", "items: scan + barrier"]
+else:
+    names = ["tile (ticket / workgroup index) + group geometry", "-", "gather k through the runs", "wait for the other waves", "-", "phase 1 (bit strings)", "sync", "look-back + sync", "phase 2 (window, stores)", "run table + pixels: loads, staging", "barrier"]
 print("blocking call %.3f ms; %d tiles stamped; s_memtime ticks per tile (thread 0):" % (dt * 1e3, cnt))
 tot = sum(v[:11])
 for i, nm in enumerate(names):
-    print("  %-26s %9.0f  %5.1f %%" % (nm, v[i] / cnt, 100.0 * v[i] / tot))
+    if nm != "-":
+        print("  %-50s %9.0f  %5.1f %%" % (nm, v[i] / cnt, 100.0 * v[i] / tot))
 print("  total %.0f ticks per tile" % (tot / cnt))
 enc.close()

@@ -137,6 +137,8 @@ struct felics_ctx {
     int stage_launches[ST_COUNT] = {};
     DevBuf in, out;  // staging of the host-pointer entry points
     DevBuf dec_meta, dec_planes;  // GPU decoder: offsets | lens | status of a batch; Y / Co / Cg planes of RGB streams
+    DevBuf dec_table;             // 16-bit streams: estimator tables in HBM (8.4 MB per stream of a pass), zeroed once, rows tagged with an epoch
+    uint32_t dec_epoch = 0;       // last epoch handed out (three per call: one per plane)
 };
 
 namespace {
@@ -984,6 +986,7 @@ void felics_ctx_destroy(felics_ctx *ctx) {
     release(ctx->out);
     release(ctx->dec_meta);
     release(ctx->dec_planes);
+    release(ctx->dec_table);
     delete ctx;
 }
 
@@ -1187,6 +1190,45 @@ int felics_decompress_batch_device(felics_ctx *ctx, size_t n, const void *d_stre
     if (frame_bytes && !d_pixels) return fail_all(FELICS_E_INVALID_ARGUMENT);
     // a stream of this shape is never longer than this: a caller's length beyond it is not a stream (and not a size to allocate)
     const uint64_t max_len = felics_max_compressed_size(hdr.width, hdr.height, hdr.color_type, hdr.pixel_depth);
+    if (bps == 2 && decode16_lds_bytes(hdr.width) <= DECODE_LDS_LIMIT && !getenv("FELICS_DECODE16_HOST")) {
+        // 16-bit streams on the device: passes of at most DEC16_PASS streams (a stream's estimator table is 8.4 MB of HBM)
+        constexpr size_t DEC16_PASS = 1024;
+        const size_t per = std::min(n, DEC16_PASS);
+        const size_t table_bytes = decode16_table_bytes((uint32_t)per);
+        if (table_bytes > ctx->dec_table.cap) ctx->dec_epoch = 0;  // a fresh (zeroed) buffer: epochs start over
+        if ((rc = reserve_zeroed(ctx, ctx->dec_table, table_bytes)) != 0) return fail_all(rc);
+        if ((rc = reserve(ctx, ctx->dec_meta, per * 8 * 2 + per * 4)) != 0) return fail_all(rc);
+        int32_t *d_planes32 = nullptr;
+        if (planes == 3) {
+            if ((rc = reserve(ctx, ctx->dec_planes, (size_t)(npix * 3 * 4 * per) + 64)) != 0) return fail_all(rc);
+            d_planes32 = (int32_t *)ctx->dec_planes.p;
+        }
+        hipStream_t s = l.stream;
+        for (size_t i = 0; i < n; i++) status[i] = FELICS_E_HIP;  // until the kernel's own word arrives
+        int first_rc = FELICS_OK;
+        for (size_t first = 0; first < n; first += per) {
+            const size_t cnt = std::min(per, n - first);
+            if (ctx->dec_epoch > 0xFFFFFFF0u) {  // epochs used up: clear the tables, start over
+                HIP_TRY(ctx, hipMemsetAsync(ctx->dec_table.p, 0, ctx->dec_table.cap, s));
+                ctx->dec_epoch = 0;
+            }
+            const uint32_t epoch0 = ctx->dec_epoch + 1;
+            ctx->dec_epoch += 3;
+            uint64_t *d_off = (uint64_t *)ctx->dec_meta.p, *d_len = d_off + cnt;
+            int *d_status = (int *)(d_len + cnt);
+            HIP_TRY(ctx, hipMemcpyAsync(d_off, offsets + first, cnt * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipMemcpyAsync(d_len, lens + first, cnt * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipMemsetAsync(d_status, 0xFF, cnt * 4, s));
+            HIP_TRY(ctx, launch_decode16(s, (const uint8_t *)d_streams, d_off, d_len, (uint32_t)cnt, hdr.width, hdr.height, hdr.color_type,
+                                         (uint16_t *)d_pixels + first * (frame_bytes / 2), d_planes32, (uint32_t *)ctx->dec_table.p, epoch0,
+                                         d_status));
+            HIP_TRY(ctx, hipMemcpyAsync(status + first, d_status, cnt * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            for (size_t i = first; i < first + cnt && !first_rc; i++)
+                if (status[i]) first_rc = status[i];
+        }
+        return first_rc;
+    }
     if (bps == 2 || decode8_lds_bytes(hdr.width, hdr.color_type) > DECODE_LDS_LIMIT) {
         // host decoder, stream by stream
         std::vector<uint8_t> sbuf, pbuf;

@@ -305,6 +305,230 @@ __global__ __launch_bounds__(256) void k_ycocg8_to_rgb(const int16_t *__restrict
     if (bad) atomicCAS(&status[img], FELICS_OK, FELICS_E_INVALID_VALUE);
 }
 
+// ------------------------------------------------------------------------------------------
+// 16-bit streams (traits.rs:35-43: fifteen Rice parameters, contexts 0 .. 131 070).
+//
+// The same walk, one wave per stream, with the estimator table where it fits: in HBM, 131 071 rows of sixteen words per
+// stream (fifteen counters + the EPOCH the row was last written in: a row of another epoch reads as zeros, so the table
+// is never cleared between planes, streams or calls), behind a direct-mapped write-back cache of DEC16_SLOTS rows in LDS
+// (a plane uses a few thousand contexts, a few dozen of them for most of its events).  A row lives one counter per lane
+// (lanes 0 .. 14): get_k and the update's minimum are DPP reductions over one row of sixteen lanes, everything else about
+// a pixel is scalar code as in k_decode8.  Gray: u16 pixels straight out; RGB: Y / Co / Cg as int32 planes + k_ycocg16_to_rgb.
+// ------------------------------------------------------------------------------------------
+
+constexpr uint32_t DEC16_SLOTS = 512;                 // cached rows: 32 KB of LDS
+constexpr uint32_t DEC16_ROW = 16;                    // words per row (15 counters, epoch)
+constexpr uint32_t DEC16_CONTEXTS = 2u * 65535u + 1u;  // MAX_CONTEXT + 1 (traits.rs:38)
+
+// minimum over lanes 0 .. 15 (one DPP row), left in lane 15, returned wave-uniform
+__device__ __forceinline__ uint32_t row16_min(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x111, 0xF, 0xF, false));  // row_shr:1
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x112, 0xF, 0xF, false));  // row_shr:2
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x114, 0xF, 0xF, false));  // row_shr:4
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x118, 0xF, 0xF, false));  // row_shr:8
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+}
+
+__global__ __launch_bounds__(64) void k_decode16(const uint8_t *__restrict__ streams, const uint64_t *__restrict__ offsets,
+                                                 const uint64_t *__restrict__ lens, uint32_t W, uint32_t H, uint32_t color,
+                                                 uint16_t *__restrict__ pixels, int32_t *__restrict__ planes,
+                                                 uint32_t *__restrict__ gtable, uint32_t epoch0, int *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *crow = reinterpret_cast<uint32_t *>(smem);                       // [DEC16_SLOTS][DEC16_ROW] cached rows
+    uint32_t *ctag = crow + DEC16_SLOTS * DEC16_ROW;                            // [DEC16_SLOTS] context held (or ~0)
+    int32_t *rows = reinterpret_cast<int32_t *>(ctag + DEC16_SLOTS);
+    const uint32_t rstride = decode8_row_stride(W);
+    const uint32_t img = blockIdx.x, lane = lane_id();
+    const uint8_t *s = streams + offsets[img];
+    const uint64_t slen = lens[img];
+    const uint64_t npix = (uint64_t)W * H;
+    const uint32_t nplanes = color ? 3u : 1u;
+    uint32_t *table = gtable + (uint64_t)img * DEC16_CONTEXTS * DEC16_ROW;
+    int rc = FELICS_OK;
+    if (slen < FELICS_HEADER_BYTES) {
+        rc = FELICS_E_IO;
+    } else {
+        const uint32_t w = ((uint32_t)s[6] << 24) | ((uint32_t)s[7] << 16) | ((uint32_t)s[8] << 8) | s[9];
+        const uint32_t h = ((uint32_t)s[10] << 24) | ((uint32_t)s[11] << 16) | ((uint32_t)s[12] << 8) | s[13];
+        if (s[0] != 'F' || s[1] != 'L' || s[2] != 'C' || s[3] != 'S') rc = FELICS_E_INVALID_SIGNATURE;
+        else if (s[4] > 1) rc = FELICS_E_INVALID_COLOR_TYPE;
+        else if (s[5] > 1) rc = FELICS_E_INVALID_PIXEL_DEPTH;
+        else if (s[4] != color || s[5] != 1 || w != W || h != H) rc = FELICS_E_INVALID_DIMENSIONS;
+    }
+    rc = unii(rc);
+    if (rc != FELICS_OK) {
+        if (lane == 0) status[img] = rc;
+        return;
+    }
+    ScalarBits br;
+    br.init(s + FELICS_HEADER_BYTES, slen - FELICS_HEADER_BYTES);
+    for (uint32_t c = 0; c < nplanes && rc == FELICS_OK; c++) {
+        const int32_t p0 = (int32_t)br.get(32), p1 = (int32_t)br.get(32);  // compression.rs:166-167
+        if (br.failed()) {
+            rc = FELICS_E_IO;
+            break;
+        }
+        if (npix == 0) continue;
+        const uint32_t epoch = epoch0 + c;  // KEstimator::new: rows of other epochs read as zeros
+        for (uint32_t i = lane; i < DEC16_SLOTS; i += 64) ctag[i] = 0xFFFFFFFFu;  // (nothing to write back: the last plane's rows are dead)
+        __builtin_amdgcn_wave_barrier();
+        int32_t *outp = planes ? planes + ((uint64_t)img * nplanes + c) * npix : nullptr;
+        uint16_t *outg = planes ? nullptr : pixels + (uint64_t)img * npix;
+        const int lo_ok = (color && c > 0) ? -65535 : 0, hi_ok = 65535;  // Y 0..65535, Co / Cg -65535..65535
+        uint32_t x = 0, y = 0;
+        int32_t *cur = rows, *prev = rows + rstride;
+        int upv = 0;   // VECTOR: prev[xb + lane] for the 64-sample block xb the walk stands in
+        int rowv = 0;  // VECTOR: the samples of this block decoded so far
+        int left = 0, left2 = 0;
+        int first_col2 = 0;
+        for (uint64_t i = 0; i < npix; i++) {
+            const uint32_t xl = x & 63u;
+            if (xl == 0) {
+                if (y > 0) upv = (int)prev[x + lane];
+                if (x == 0 && y > 0) first_col2 = y >= 2 ? unii((int)cur[0]) : (W > 1 ? __builtin_amdgcn_readlane(upv, 1) : 0);
+            }
+            int pv;
+            if (i < 2) {
+                pv = i == 0 ? p0 : p1;
+            } else {
+                const int above = __builtin_amdgcn_readlane(upv, (int)xl);
+                const bool row0 = y == 0, col0 = x == 0 && !row0;
+                const int v1 = col0 ? above : left;
+                const int v2 = col0 ? first_col2 : (row0 ? left2 : above);
+                const int hi = max(v1, v2), lo = min(v1, v2);
+                const uint32_t ctx = (uint32_t)(hi - lo);  // <= 131 070 because every stored sample is in range
+                br.refill();  // >= 33 bits: an in-range code has at most 18, the two flags of the other kind 2
+                if (br.take(1)) {  // in range: phased-in code of p - L (phase_in_coding.rs:86-112)
+                    const uint32_t n = ctx + 1;
+                    const uint32_t m = 31u - (uint32_t)__builtin_clz(n);
+                    const uint32_t right_p = (2u << m) - n, left_p = n - (1u << m);
+                    uint32_t r = br.take(m);
+                    const uint32_t longer = r >= right_p ? 1u : 0u;
+                    const uint32_t r2 = (r - right_p) * 2u + right_p + br.take(longer);
+                    r = longer ? r2 : r;
+                    uint32_t rot = r + left_p;
+                    rot = rot >= n ? rot - n : rot;
+                    pv = lo + (int)rot;
+                } else {
+                    const bool above_flag = br.take(1) != 0;
+                    // the context's row: lane k < 15 holds counter k
+                    const uint32_t slot = ctx & (DEC16_SLOTS - 1u);
+                    const uint32_t held = uni(ctag[slot]);
+                    uint32_t S;
+                    if (held == ctx) {
+                        S = crow[slot * DEC16_ROW + (lane & 15u)];
+                    } else {
+                        if (held != 0xFFFFFFFFu && lane < DEC16_ROW)  // write the row this slot held back (its epoch word with it)
+                            table[(uint64_t)held * DEC16_ROW + lane] = crow[slot * DEC16_ROW + lane];
+                        // (read from L2, not from this CU's L1: the row may be one this wave wrote back a while ago; that store
+                        // has been acknowledged by now -- every load's wait covers the stores before it)
+                        uint32_t g = lane < DEC16_ROW ? __hip_atomic_load(&table[(uint64_t)ctx * DEC16_ROW + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                        const uint32_t row_epoch = (uint32_t)__builtin_amdgcn_readlane((int)g, 15);
+                        g = row_epoch == epoch ? g : 0u;  // a row of another plane / call: fresh
+                        S = (uint32_t)__shfl((int)g, (int)(lane & 15u));  // every row of sixteen lanes holds the counters
+                        if (lane == 0) ctag[slot] = ctx;
+                    }
+                    // get_k: smallest counter, ties to the largest k (parameter_selection.rs:71-85)
+                    const uint32_t l15 = lane & 15u;
+                    const uint32_t key = l15 < 15u ? (S << 4) | (15u - l15) : 0xFFFFFFFFu;
+                    const uint32_t k = 15u - (row16_min(key) & 15u);
+                    const uint64_t q = br.unary0();
+                    const uint64_t e64 = (q << k) + br.get(k);
+                    if (e64 > 262144u) {  // no sample of a 16-bit plane is that far from its neighbours
+                        rc = e64 > 0xFFFFFFFFull ? FELICS_E_VALUE_OVERFLOW : FELICS_E_INVALID_VALUE;
+                        break;
+                    }
+                    const uint32_t e = (uint32_t)e64;
+                    uint32_t S2 = S + (e >> l15) + 1u + l15;                       // update (rice_coding.rs:56-58 lengths)
+                    const uint32_t mn = row16_min(l15 < 15u ? S2 : 0xFFFFFFFFu);
+                    S2 = mn > 1024u ? S2 >> 1 : S2;                                // x /= 2 on every counter
+                    if (lane < DEC16_ROW) crow[slot * DEC16_ROW + lane] = lane < 15u ? S2 : epoch;
+                    pv = above_flag ? hi + (int)e + 1 : lo - (int)e - 1;
+                }
+            }
+            if (pv < lo_ok || pv > hi_ok) {
+                rc = FELICS_E_INVALID_VALUE;
+                break;
+            }
+            rowv = lane == xl ? pv : rowv;
+            left2 = left;
+            left = pv;
+            const bool row_end = x + 1 == W;
+            if (xl == 63u || row_end) {
+                const uint32_t xb = x & ~63u;
+                if (xb + lane <= x) {
+                    cur[xb + lane] = rowv;
+                    if (outg)
+                        outg[(uint64_t)y * W + xb + lane] = (uint16_t)rowv;
+                    else
+                        outp[(uint64_t)y * W + xb + lane] = rowv;
+                }
+            }
+            if (row_end) {
+                if (br.failed()) {
+                    rc = FELICS_E_IO;
+                    break;
+                }
+                __builtin_amdgcn_wave_barrier();
+                x = 0;
+                y++;
+                int32_t *t = cur;
+                cur = prev;
+                prev = t;
+            } else {
+                x++;
+            }
+        }
+    }
+    if (br.failed()) rc = FELICS_E_IO;
+    if (lane == 0) status[img] = rc;
+}
+
+// ycocg_to_rgb (color_transform.rs:20-26) on the decoded 16-bit planes, range-checked like try_into::<u16>()
+__global__ __launch_bounds__(256) void k_ycocg16_to_rgb(const int32_t *__restrict__ planes, uint16_t *__restrict__ pixels,
+                                                        uint32_t npix, int *__restrict__ status) {
+    const uint32_t img = blockIdx.y;
+    if (status[img] != FELICS_OK) return;
+    const int32_t *pl = planes + (uint64_t)img * 3 * npix;
+    uint16_t *dst = pixels + (uint64_t)img * 3 * npix;
+    bool bad = false;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        const int yv = pl[i], co = pl[(uint64_t)npix + i], cg = pl[2ull * npix + i];
+        const int t = yv - cg / 2;  // `/` truncates toward zero like Rust's
+        const int g = cg + t, b = t - co / 2, r = b + co;
+        if ((r | g | b) < 0 || r > 65535 || g > 65535 || b > 65535) bad = true;
+        dst[(uint64_t)i * 3] = (uint16_t)r;
+        dst[(uint64_t)i * 3 + 1] = (uint16_t)g;
+        dst[(uint64_t)i * 3 + 2] = (uint16_t)b;
+    }
+    if (bad) atomicCAS(&status[img], FELICS_OK, FELICS_E_INVALID_VALUE);
+}
+
+uint32_t decode16_lds_bytes(uint32_t W) {
+    return DEC16_SLOTS * DEC16_ROW * 4 + DEC16_SLOTS * 4 + 2u * decode8_row_stride(W) * 4u;
+}
+size_t decode16_table_bytes(uint32_t n) { return (size_t)n * DEC16_CONTEXTS * DEC16_ROW * 4; }
+
+hipError_t launch_decode16(hipStream_t s, const uint8_t *streams, const uint64_t *offsets, const uint64_t *lens, uint32_t n,
+                           uint32_t W, uint32_t H, uint32_t color, uint16_t *pixels, int32_t *planes, uint32_t *table,
+                           uint32_t epoch0, int *status) {
+    if (n == 0) return hipSuccess;
+    const uint32_t lds = decode16_lds_bytes(W);
+    if (lds > 64u * 1024u) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode16),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)DECODE_LDS_LIMIT);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_decode16, dim3(n), dim3(64), lds, s, streams, offsets, lens, W, H, color, pixels, planes, table, epoch0,
+                       status);
+    if (color) {
+        const uint64_t npix = (uint64_t)W * H;
+        const uint32_t bx = (uint32_t)std::min<uint64_t>((npix + 255) / 256, 1024u);
+        if (bx) hipLaunchKernelGGL(k_ycocg16_to_rgb, dim3(bx, n), dim3(256), 0, s, planes, pixels, (uint32_t)npix, status);
+    }
+    return hipGetLastError();
+}
+
 uint32_t decode8_lds_bytes(uint32_t W, uint32_t color) {
     return (color ? nctx_of<int16_t>() : nctx_of<uint8_t>()) * 6 * 4 + 2u * decode8_row_stride(W) * 2u;
 }

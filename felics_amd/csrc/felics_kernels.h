@@ -211,6 +211,13 @@ constexpr uint32_t DECODE_LDS_LIMIT = 160u * 1024u;  // LDS of one CU (MI355X_MI
 // ---- GPU decoder for 8-bit streams (felics_gpudecode.hip): one wave per stream.  status[i] = FELICS_OK or an error
 // code; gray pixels go straight to `pixels`, RGB through int16 planes (image i at i * 3 * npix) + a conversion kernel.
 uint32_t decode8_lds_bytes(uint32_t W, uint32_t color);
+// 16-bit streams: the estimator tables live in HBM (decode16_table_bytes(n): 8.4 MB per stream, zero-initialised ONCE: rows carry
+// the epoch they were written in; a call uses epochs epoch0 .. epoch0 + 2, never 0 and never reused on the same buffer)
+uint32_t decode16_lds_bytes(uint32_t W);
+size_t decode16_table_bytes(uint32_t n);
+hipError_t launch_decode16(hipStream_t s, const uint8_t *streams, const uint64_t *offsets, const uint64_t *lens, uint32_t n,
+                           uint32_t W, uint32_t H, uint32_t color, uint16_t *pixels, int32_t *planes, uint32_t *table,
+                           uint32_t epoch0, int *status);
 hipError_t launch_decode8(hipStream_t s, const uint8_t *streams, const uint64_t *offsets, const uint64_t *lens, uint32_t n,
                           uint32_t W, uint32_t H, uint32_t color, uint8_t *pixels, int16_t *planes, int *status);
 

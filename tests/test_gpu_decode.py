@@ -49,10 +49,11 @@ DIMS = [(2, 1), (1, 2), (1, 1), (4, 7), (100, 40), (124, 274), (1447, 8), (44, 1
 
 
 def test_roundtrip_reference_shapes(enc, oracle):
-    """compression.rs:500-558: random u8 gray and rgb (and u16 through the host fallback) at the reference's shapes."""
+    """compression.rs:500-558: random u8 / u16 gray and rgb at the reference's shapes (16-bit streams on the device too:
+    k_decode16, the estimator table in HBM behind an LDS cache)."""
     rng = np.random.default_rng(5)
     for w, h in DIMS:
-        for shape, dt, mx in (((h, w), np.uint8, 256), ((h, w, 3), np.uint8, 256), ((h, w), np.uint16, 65536)):
+        for shape, dt, mx in (((h, w), np.uint8, 256), ((h, w, 3), np.uint8, 256), ((h, w), np.uint16, 65536), ((h, w, 3), np.uint16, 65536)):
             imgs = [rng.integers(0, mx, size=shape).astype(dt) for _ in range(3)]
             smooth = (np.add.outer(np.arange(h), np.arange(w)) // 2 % mx).astype(dt)
             imgs.append(smooth if len(shape) == 2 else np.stack([smooth, smooth[::-1], (mx - 1) - smooth], -1).copy())
@@ -178,3 +179,66 @@ def test_baseline_batch_decodes(enc):
     d_px = torch.zeros_like(frames)
     _, status = enc.decompress_batch_device(d_out.data_ptr(), offs, lens, d_px.data_ptr(), d_px.numel())
     assert (status == 0).all() and bool((d_px == frames).all())
+
+
+
+def test_sixteen_bit_streams_on_the_device(enc, oracle):
+    """16-bit streams never leave the GPU: natural 16-bit files (the golden ones, 256 x 256 and 1081 x 1081), synthetic gray16 and
+    rgb16 frames with more contexts than the LDS cache has rows (evictions, write-backs, reloads), extreme content (65 534-bit
+    codes), two calls in a row on the same tables (epochs), corrupt streams -- against the original pixels and the host decoder."""
+    import felics_amd
+    import torch
+    from PIL import Image
+    from felics_amd import synth
+
+    rng = np.random.default_rng(12)
+    for name in ("aerial.tiff", "man.tiff", "heightmap.tiff"):
+        img = np.array(Image.open(os.path.join(GOLDEN, name)))
+        assert img.dtype == np.uint16
+        stream = open(os.path.join(GOLDEN, name + ".felics"), "rb").read()
+        for _ in range(2):  # the second call finds the first one's rows in the tables: another epoch
+            _, back = _decode_batch(enc, [stream, stream], img.shape, np.uint16)
+            assert (back[0] == img).all() and (back[1] == img).all(), name
+    frames = [synth.gray16(640, 360, f) for f in range(5)] + [rng.integers(0, 65536, size=(360, 640), dtype=np.uint16)]
+    _, back = _decode_batch(enc, [oracle.compress(f) for f in frames], (360, 640), np.uint16)
+    assert all((b == f).all() for b, f in zip(back, frames))
+    rgb = [np.stack([f, np.roll(f, 3, axis=1), 65535 - f], -1).copy() for f in frames[:3]] + [rng.integers(0, 65536, size=(360, 640, 3), dtype=np.uint16)]
+    _, back = _decode_batch(enc, [oracle.compress(f) for f in rgb], (360, 640, 3), np.uint16)
+    assert all((b == f).all() for b, f in zip(back, rgb))
+    quiet = np.full((40, 300), 9, np.uint16)
+    spikes = quiet.copy()
+    spikes[rng.integers(0, 40, 60), rng.integers(0, 300, 60)] = 65535  # unary runs of 65 525 ones at k = 0
+    _, back = _decode_batch(enc, [oracle.compress(quiet), oracle.compress(spikes)], (40, 300), np.uint16)
+    assert (back[0] == quiet).all() and (back[1] == spikes).all()
+    # corrupt 16-bit streams: a status for every stream, the good ones intact
+    img = frames[0][:50, :70].copy()
+    good = oracle.compress(img)
+    bad = [good[: len(good) // 2], good[:4] + b"\x07" + good[5:], good[:30] + b"\xff" * (len(good) - 30)]
+    for _ in range(8):
+        b = bytearray(good)
+        b[int(rng.integers(14, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        bad.append(bytes(b))
+    streams = [good] + bad + [good]
+    offs, blob = [], bytearray()
+    for s_ in streams:
+        offs.append(len(blob))
+        blob += s_ + bytes((-len(s_)) % 16)
+    d_in = torch.from_numpy(np.frombuffer(bytes(blob) + bytes(16), dtype=np.uint8).copy()).cuda()
+    d_px = torch.zeros(img.size * 2 * len(streams), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with pytest.raises(felics_amd.DecompressionError) as ei:
+        enc.decompress_batch_device(d_in.data_ptr(), offs, [len(s_) for s_ in streams], d_px.data_ptr(), d_px.numel())
+    status = ei.value.status
+    host = d_px.cpu().numpy().view(np.uint16)
+    assert status[0] == 0 and status[-1] == 0 and status[1] == -1 and status[2] == -5
+    assert (host[: img.size].reshape(img.shape) == img).all() and (host[-img.size:].reshape(img.shape) == img).all()
+    for i, s_ in enumerate(streams[1:-1], start=1):
+        try:
+            want = oracle.decompress(s_)
+            host_ok = want.shape == img.shape and want.dtype == np.uint16
+        except Exception:
+            host_ok = False
+        if not host_ok:
+            assert status[i] != 0, i
+        elif status[i] == 0:
+            assert (host[i * img.size:(i + 1) * img.size].reshape(img.shape) == want).all(), i

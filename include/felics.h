@@ -138,7 +138,7 @@ int felics_decompress_with_header(const uint8_t *in, size_t len, const felics_he
  * error).  *hdr (optional) receives the header all streams must share; it is read from stream 0.
  * Replaces n calls of `decompress_image` (compression.rs:420-441).  The format is bit-serial per stream (and the
  * planes of an RGB image share one bit stream), so the only parallelism is across streams: one wave per stream
- * for 8-bit data.  16-bit streams (a 7.9 MB estimator table per plane) are decoded by the host decoder and copied.
+ * for 8-bit and for 16-bit data (k_decode16: a 8.4 MB estimator table per stream in device memory, rows tagged with an epoch).
  * status[] is written for all n streams on every return (a call that ends before decoding -- bad header of stream 0, buffer too
  * small, a HIP error -- puts its own code in every entry).  The kernel loads a stream as whole ALIGNED 32-bit words: it may
  * touch up to three bytes on either side of a stream, always inside an aligned word that also holds a byte of the stream,

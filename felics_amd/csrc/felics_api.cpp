@@ -97,6 +97,7 @@ struct felics_ctx {
     // i + 1 underneath.  Built and measured in round 3: the kernels do run at their stand-alone speed, and the step is no
     // shorter (see sched_shared) -- the default stays per-lane streams, everything side by side.
     hipStream_t tstream = nullptr;
+    int defer_depth = 1;        // FELICS_DEFER
     bool sched_shared = false;  // (measured round 3: 3.28-3.36 ms per step shared against 3.09-3.14 with per-lane streams: the spine of batch i + 1 -- its
                                 // helper waves sum every block of every chain -- takes a fifth of the issue slots from whatever runs beside it either way)
     int next_lane = 0;          // lane of the next felics_submit_batch_device
@@ -910,6 +911,7 @@ int felics_ctx_create(int device, felics_ctx **out) {
         if (strcmp(e, "tailonly") == 0) prio_spine = prio_front = prio_low, prio_tail = prio_high;
     }
     if (const char *e = getenv("FELICS_SCHED")) ctx->sched_shared = strcmp(e, "shared") == 0;
+    if (const char *e = getenv("FELICS_DEFER")) ctx->defer_depth = std::max(1, atoi(e));
     ok = ok && hipStreamCreateWithPriority(&ctx->tstream, hipStreamNonBlocking, prio_front) == hipSuccess;
     for (int li = 0; li < ctx->nlanes; li++) {
         Lane &l = ctx->lanes[li];
@@ -1050,8 +1052,11 @@ int felics_submit_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels, 
             return rc;
         }
         l.tail_pending = defer;
-        // behind this batch's front: the tails (k + pack) of the batches submitted before it (lanes L + 1 .. L - 1, oldest first)
-        if (ctx->nlanes > 1 && (rc = flush_tails(ctx, (L + 1) % ctx->nlanes, (L + ctx->nlanes - 1) % ctx->nlanes)) != 0) return rc;
+        // behind this batch's front: the tails (k + pack) of the batches submitted `defer_depth` and more submissions ago (oldest
+        // first); depth 1: front of batch i + 1, tail of batch i; depth 2 (three lanes or more): front i + 2, tail i -- the spine
+        // of a batch then has two steps to finish before its tail is due
+        const int depth = std::max(1, std::min(ctx->defer_depth, ctx->nlanes - 1));
+        if (ctx->nlanes > depth && (rc = flush_tails(ctx, (L + 1) % ctx->nlanes, (L + ctx->nlanes - depth) % ctx->nlanes)) != 0) return rc;
     }
     l.pending = true;
     *ticket = L;

@@ -339,10 +339,14 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
             m_hi &= ~((uint32_t)(bb >> 32) ^ t);
         };
 #pragma unroll
-        for (uint32_t b = 0; b < 5; b++) match_bit(b);
-        if (__ballot(ev && c >= 32u) != 0) {  // contexts are < 512
+        for (uint32_t b = 0; b < 3; b++) match_bit(b);
+        if (__ballot(ev && c >= 8u) != 0) {  // (a smooth frame's batches hold contexts 0 .. 7 only: three bits do)
+            match_bit(3);
+            match_bit(4);
+            if (__ballot(ev && c >= 32u) != 0) {  // contexts are < 512
 #pragma unroll
-            for (uint32_t b = 5; b < 9; b++) match_bit(b);
+                for (uint32_t b = 5; b < 9; b++) match_bit(b);
+            }
         }
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
         const uint32_t group = (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);

@@ -1869,6 +1869,9 @@ __device__ __forceinline__ void pack_tile_fused(TileLDS<T> &tl, const uint8_t *k
         lb.finish();
     }
     const uint32_t bits = lb.total;
+#if defined(FELICS_PACK_STOP) && FELICS_PACK_STOP == 3
+    if (bits != 0x12345678u) return;  // (the strings are built, nothing is done with them)
+#endif
     const uint32_t inc = wave_incl_scan(bits);
     if (lane == 63) wsum[wave] = inc;
     PSTAMP(5);
@@ -1940,6 +1943,9 @@ __device__ __forceinline__ void pack_tile_fused(TileLDS<T> &tl, const uint8_t *k
     }
     __syncthreads();
     PSTAMP(7);
+#if defined(FELICS_PACK_STOP) && FELICS_PACK_STOP == 4
+    return;
+#endif
     const uint64_t tile_lo = tile_lo_sh, tile_hi = tile_lo + tile_total;
     const uint64_t my_lo = tile_lo + woff + inc - bits;
     uint64_t limit_words;  // a stream that outgrows its slot is cut (the host re-packs)
@@ -1995,15 +2001,20 @@ __device__ __forceinline__ void pack_tile_fused(TileLDS<T> &tl, const uint8_t *k
             bw.finish();
         }
         __syncthreads();
+        // plain stores for the words the tile has to itself: r in [lo, hi) -- one compare per word; the tile's first and last
+        // word, where they are shared with its neighbours, go to the edge arrays (k_join_edges) by thread 0 afterwards
+        const uint32_t lo = first_shared ? 1u : 0u;
+        const uint32_t hi = min(nwords - (last_shared ? 1u : 0u), limit_rel);
+        const uint32_t span = hi > lo ? hi - lo : 0u;
 #pragma unroll
         for (uint32_t u = 0; u < FUSED_WIN_WORDS / PACK_THREADS; u++) {
             const uint32_t j = threadIdx.x + u * PACK_THREADS, r = wb + j;  // word r of the tile
-            const uint32_t v = win[j];
-            // the tile's first and last word may be shared with its neighbours: those go to the edge arrays (k_join_edges)
-            const bool is_first = r == 0 && first_shared, is_last = r == nwords - 1u && last_shared;
-            if (r < nwords && !is_first && !is_last && r < limit_rel) out_rel[r] = __builtin_bswap32(v);
-            if (is_first) edge_first[(uint64_t)plane * ntiles + tile] = v;  // merged with the previous tile's last word later
-            else if (is_last && r < nwords) edge_last[(uint64_t)plane * ntiles + tile] = v;
+            if (r - lo < span) out_rel[r] = __builtin_bswap32(win[j]);
+        }
+        if (threadIdx.x == 0) {
+            if (wb == 0 && first_shared) edge_first[(uint64_t)plane * ntiles + tile] = win[0];  // merged with the previous tile's last word later
+            const uint32_t rl = nwords - 1u;
+            if (last_shared && !(rl == 0 && first_shared) && rl >= wb && rl - wb < FUSED_WIN_WORDS) edge_last[(uint64_t)plane * ntiles + tile] = win[rl - wb];
         }
     }
     PSTAMP(8);
@@ -2244,6 +2255,9 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 5))) __global__ __launch
         }
     }
     PSTAMP(9);
+#if defined(FELICS_PACK_STOP) && FELICS_PACK_STOP == 1
+    return;  // (diagnostic builds: instruction counts of the kernel's stages, profiles/tools/pack_stages.sh)
+#endif
     __syncthreads();
     PSTAMP(10);
     // wave w takes contexts w, w + 4, w + 8, ...: the contexts that matter in a smooth frame are the first ten.
@@ -2255,55 +2269,50 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 5))) __global__ __launch
     for (uint32_t h = 0; h < NC / (64 * NWV); h++) {
         const uint32_t c = h * 64 * NWV + lane * NWV + wave;
         const uint32_t a = run_a[c], n = run_n[c];
-        {  // short runs: lane = run
+        // (Loads and LDS stores are not predicated lane by lane: a lane past the end of its run / chunk takes the last element
+        // again -- the same k goes to the same pixel twice -- so a whole group of loads runs under ONE condition; lane-wise
+        // predicates were four scalar instructions per load, 140 M scalar instructions per step in this stage.)
+        const bool is_short = n != 0 && n <= GATHER_SHORT;
+        if (is_short) {  // short runs: lane = run
             uint32_t kv[GATHER_SHORT], pv[GATHER_SHORT];
-            const bool is_short = n <= GATHER_SHORT;
-            if (__ballot(is_short && n != 0) != 0) {
 #pragma unroll
-                for (uint32_t u = 0; u < GATHER_SHORT; u++) {
-                    kv[u] = pv[u] = 0;
-                    if (is_short && u < n) {
-                        kv[u] = gs.k_sorted[(uint64_t)a + u];
-                        pv[u] = gs.pix_of[(uint64_t)a + u];
-                    }
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < GATHER_SHORT; u++)
-                    if (is_short && u < n) kq[pv[u]] = (uint8_t)kv[u];
+            for (uint32_t u = 0; u < GATHER_SHORT; u++) {
+                const uint64_t at = (uint64_t)a + min(u, n - 1u);
+                kv[u] = gs.k_sorted[at];
+                pv[u] = gs.pix_of[at];
             }
+#pragma unroll
+            for (uint32_t u = 0; u < GATHER_SHORT; u++) kq[pv[u]] = (uint8_t)kv[u];
         }
         uint64_t longs = __ballot(n > GATHER_SHORT);
         uint32_t off = 0;  // events of the first run of `longs` already taken
         while (longs) {
-            uint32_t base[GATHER_CHUNKS], cnt[GATHER_CHUNKS];
+            uint32_t kv[GATHER_CHUNKS], pv[GATHER_CHUNKS], live = 0;
 #pragma unroll
-            for (uint32_t u = 0; u < GATHER_CHUNKS; u++) {  // (wave-uniform: scalar registers)
-                const bool valid = longs != 0;
-                const uint32_t b = valid ? (uint32_t)__builtin_ctzll(longs) : 0u;
-                const uint32_t A = readlane(a, b), N = readlane(n, b);
-                base[u] = A + off;
-                cnt[u] = valid ? min(64u, N - off) : 0u;
-                off += 64;
-                if (valid && off >= N) {
-                    longs &= longs - 1;
-                    off = 0;
-                }
-            }
-            uint32_t kv[GATHER_CHUNKS], pv[GATHER_CHUNKS];
-#pragma unroll
-            for (uint32_t u = 0; u < GATHER_CHUNKS; u++) {
-                kv[u] = pv[u] = 0;
-                if (lane < cnt[u]) {
-                    kv[u] = gs.k_sorted[(uint64_t)base[u] + lane];
-                    pv[u] = gs.pix_of[(uint64_t)base[u] + lane];
+            for (uint32_t u = 0; u < GATHER_CHUNKS; u++) {  // (wave-uniform: scalar registers and scalar branches)
+                if (longs != 0) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(longs);
+                    const uint32_t A = readlane(a, b), N = readlane(n, b);
+                    const uint64_t at = (uint64_t)A + min(off + lane, N - 1u);
+                    kv[u] = gs.k_sorted[at];
+                    pv[u] = gs.pix_of[at];
+                    live = u + 1;
+                    off += 64;
+                    if (off >= N) {
+                        longs &= longs - 1;
+                        off = 0;
+                    }
                 }
             }
 #pragma unroll
             for (uint32_t u = 0; u < GATHER_CHUNKS; u++)
-                if (lane < cnt[u]) kq[pv[u]] = (uint8_t)kv[u];
+                if (u < live) kq[pv[u]] = (uint8_t)kv[u];
         }
     }
     PSTAMP(2);
+#if defined(FELICS_PACK_STOP) && FELICS_PACK_STOP == 2
+    return;
+#endif
     __syncthreads();
     PSTAMP(3);
     if (st < pack_tile_end) pack_tile_fused<T>(tl, kq, fl, planes, nullptr, fa, st, plane, gg);

@@ -33,7 +33,7 @@ lib.felics_debug_spine_stamps(buf, 0)
 v = [x / R for x in buf]
 names = ["waiting at the batch barrier", "block steps without a halving", "prefix reads + first threshold round", "halving update + further rounds"]
 halv, blocks, batches, total = v[4], v[5], v[6], v[7]
-print("%d frame(s), blocking call %.3f ms; walker of chain (plane 0, context 1): %.0f halvings, %.0f blocks, %.0f batches, %.0f ticks (%.3f ms at 100 MHz... ticks are shader cycles)" % (n, dt * 1e3, halv, blocks, batches, total, 0))
+print("%d frame(s), blocking call %.3f ms; walker of chain (plane 0, context 1): %.0f halvings, %.0f blocks, %.0f hand-overs, %.0f ticks (shader cycles; the stamps themselves cost about as much as a block step)" % (n, dt * 1e3, halv, blocks, batches, total))
 for i, nm in enumerate(names):
     print("  %-40s %10.0f ticks  %5.1f %%  %7.1f per halving" % (nm, v[i], 100.0 * v[i] / total, v[i] / halv))
 print("  %-40s %10.0f ticks per halving" % ("total", total / halv))

@@ -61,7 +61,7 @@ struct Lane {
     size_t h_sizes_cap = 0;
     DevBuf planes, counts, chain_len, chain_base, chain_prog, scalars, sorted_e, pix_of, k_map, k_sorted, block_state, group_bits,
         tile_bits, tile_bitoff, plane_sums, image_bytes, image_off, partial, block_tag, status, edge_first, edge_last, pscratch;
-    DevBuf wrecs[2], wtile_cnt, wmeta, whist, wdigtot, heads;  // 16-bit samples: event records (sort double buffer), tile counts, plane ranges, digit histograms, chain heads
+    DevBuf wrecs[2], wtile_cnt, wmeta, whist, wdigtot, heads, wlong;  // 16-bit samples: event records (sort double buffer), tile counts, plane ranges, digit histograms, chain heads
     uint32_t epoch = 0;               // sub-batches this lane has run: block tags are (epoch, slice)
     // the submission in flight on this lane (felics_submit_batch_device .. felics_wait_batch)
     bool pending = false;
@@ -524,6 +524,10 @@ int run_wide(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     if ((rc = reserve(ctx, l.wdigtot, z.digtot_bytes)) != 0) return rc;
     if ((rc = reserve(ctx, l.heads, z.heads_bytes)) != 0) return rc;
     if ((rc = reserve(ctx, l.scalars, 64)) != 0) return rc;
+    uint32_t lane_limit = wide_lane_limit(g);
+    if (const char *e = getenv("FELICS_WIDE_LANE")) lane_limit = (uint32_t)std::max(0, atoi(e));  // tests, A/B: 0 = wave-wide only
+    const size_t nlong = wide_long_capacity(g, lane_limit);
+    if ((rc = reserve(ctx, l.wlong, nlong * (8 + 64) + 64)) != 0) return rc;
     if ((rc = reserve(ctx, l.k_map, nsamples + STAGE_PAD)) != 0) return rc;
     if ((rc = reserve(ctx, l.group_bits, (size_t)g.nplanes * g.pack_tiles * PACK_THREADS * sizeof(group_bits_t<T>))) != 0) return rc;
     if ((rc = reserve(ctx, l.tile_bits, (size_t)g.nplanes * g.pack_tiles * 4)) != 0) return rc;
@@ -559,9 +563,9 @@ int run_wide(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     }
     {
         StageTimer t(ctx, l, ST_WIDE_CHAINS, s);
-        HIP_TRY(ctx, hipMemsetAsync(nheads, 0, 4, s));
+        HIP_TRY(ctx, hipMemsetAsync(nheads, 0, 8, s));
         launch_wide_chains(s, (const uint64_t *)l.wrecs[0].p, (const uint32_t *)l.wmeta.p, (uint64_t *)l.heads.p, nheads,
-                           (uint8_t *)l.k_map.p, g);
+                           (uint8_t *)l.k_map.p, g, lane_limit, (uint64_t *)l.wlong.p, (uint32_t *)((uint64_t *)l.wlong.p + nlong));
     }
     HIP_TRY(ctx, hipMemsetAsync(plane_carry, 0, (size_t)g.nplanes * 16, s));
     {
@@ -963,7 +967,7 @@ void felics_ctx_destroy(felics_ctx *ctx) {
     for (Lane &l : ctx->lanes) {
         DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map, &l.k_sorted,
                           &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.plane_sums, &l.image_bytes, &l.image_off,
-                          &l.partial, &l.block_tag, &l.status, &l.edge_first, &l.edge_last, &l.pscratch, &l.wrecs[0], &l.wrecs[1], &l.wtile_cnt, &l.wmeta, &l.whist, &l.wdigtot, &l.heads};
+                          &l.partial, &l.block_tag, &l.status, &l.edge_first, &l.edge_last, &l.pscratch, &l.wrecs[0], &l.wrecs[1], &l.wtile_cnt, &l.wmeta, &l.whist, &l.wdigtot, &l.heads, &l.wlong};
         for (DevBuf *b : bufs) release(*b);
         if (l.h_sizes) (void)hipHostFree(l.h_sizes);
         for (int i = 0; i < ST_COUNT; i++)

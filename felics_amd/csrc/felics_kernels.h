@@ -241,8 +241,15 @@ void launch_wide_events(hipStream_t s, const T *planes, uint32_t *tile_cnt, uint
 // stable sort by context inside every plane; the result is in recs_a again
 void launch_wide_sort(hipStream_t s, uint64_t *recs_a, uint64_t *recs_b, const uint32_t *meta, uint32_t *hist, uint32_t *dig_tot,
                       const Geometry &g);
-// chain heads (nheads must be zero beforehand) and the replay of the estimator along every chain: k_map[plane * npix + i] = k
-void launch_wide_chains(hipStream_t s, const uint64_t *recs, const uint32_t *meta, uint64_t *heads, uint32_t *nheads,
-                        uint8_t *k_map, const Geometry &g);
+// chain heads and the replay of the estimator along every chain: k_map[plane * npix + i] = k.  counters = {heads, chains
+// handed over}: two words, zero beforehand.  lane_limit != 0: four lanes per chain for its first lane_limit events
+// (k_wide_chains_quad), the wave-per-chain kernel for the rest (long_heads: 8 bytes, long_state: 64 bytes per chain handed
+// over, wide_long_capacity() of them); lane_limit == 0: the wave-per-chain kernel alone.
+constexpr uint32_t WIDE_LANE_LIMIT_MIN = 4096, WIDE_LANE_LIMIT_MAX = 16384;
+constexpr uint64_t WIDE_LANE_MIN_SAMPLES = 96u << 20;  // (measured: 8 4K planes 1.28 against 1.49 ms for the wave-wide form, 16: 2.74 against 2.31, 32: 5.40 against 3.60)
+uint32_t wide_lane_limit(const Geometry &g);
+size_t wide_long_capacity(const Geometry &g, uint32_t lane_limit);
+void launch_wide_chains(hipStream_t s, const uint64_t *recs, const uint32_t *meta, uint64_t *heads, uint32_t *counters,
+                        uint8_t *k_map, const Geometry &g, uint32_t lane_limit, uint64_t *long_heads, uint32_t *long_state);
 
 }  // namespace felics

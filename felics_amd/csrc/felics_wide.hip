@@ -328,27 +328,284 @@ __global__ __launch_bounds__(WTHREADS) void k_wsort_scatter(const uint64_t *__re
 }
 
 // chain heads of the sorted records: first record of a plane, or a context different from the one before.
-// heads[h] = record index | plane << 32 (unordered)
+// heads[h] = record index | plane << 32.  A workgroup takes HEAD_TILES consecutive sort tiles, a wave 1024 consecutive
+// records of each; the workgroup reserves the places of all its heads with ONE atomic (one counter takes ~90 atomics per
+// microsecond: a batch of 16 4K frames has 45 000 waves with a head, and one atomic per such wave was 0.34 ms of waiting).
+// So the list is in (plane, context) order except for the order in which the workgroups arrive: neighbours in the list are
+// chains of neighbouring contexts, i.e. of similar length (k_wide_chains_quad relies on that for balance, not for correctness).
+constexpr uint32_t HEAD_TILES = 4;
 __global__ __launch_bounds__(WTHREADS) void k_wide_heads(const uint64_t *__restrict__ recs, const uint32_t *__restrict__ meta,
                                                          uint32_t nplanes, uint64_t *__restrict__ heads, uint32_t *__restrict__ nheads) {
-    SortTile st;
-    if (!sort_tile(meta, nplanes, blockIdx.x, st)) return;
-    const uint32_t plane_first = meta[WMETA_EV0 + st.plane];
-    for (uint32_t j0 = st.begin + (threadIdx.x & ~63u); j0 < st.end; j0 += WTHREADS) {
-        const uint32_t j = j0 + lane_id();
-        bool head = false;
-        if (j < st.end) head = j == plane_first || rec_ctx(recs[j]) != rec_ctx(recs[j - 1]);
-        const uint64_t m = __ballot(head);
-        if (m == 0) continue;
-        uint32_t base = 0;
-        if (lane_id() == 0) base = atomicAdd(nheads, (uint32_t)__popcll(m));
-        base = readlane(base, 0);
-        if (head) heads[base + mbcnt(m)] = (uint64_t)j | ((uint64_t)st.plane << 32);
+    __shared__ uint64_t masks[HEAD_TILES][WTHREADS / 64][16];  // per tile, wave and batch of 64 records: which are heads
+    __shared__ uint32_t counts[HEAD_TILES][WTHREADS / 64];
+    __shared__ uint32_t wg_base;
+    const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t *lo32 = (const uint32_t *)recs;  // the context is in the low dword of a record
+    constexpr uint32_t CTX_MASK = (1u << REC_CTX_BITS) - 1u;
+    for (uint32_t t = 0; t < HEAD_TILES; t++) {
+        SortTile st;
+        uint32_t count = 0;
+        uint64_t hm[16];
+#pragma unroll
+        for (uint32_t b = 0; b < 16; b++) hm[b] = 0;
+        if (sort_tile(meta, nplanes, blockIdx.x * HEAD_TILES + t, st) && st.begin + wave * 1024u < st.end) {
+            const uint32_t plane_first = meta[WMETA_EV0 + st.plane];
+            const uint32_t wfirst = st.begin + wave * 1024u;
+            uint32_t cur[16], prev[16];
+#pragma unroll
+            for (uint32_t b = 0; b < 16; b++) {  // (all loads before the first ballot)
+                const uint32_t jc = min(wfirst + b * 64u + lane, st.end - 1u);
+                cur[b] = lo32[2ull * jc] & CTX_MASK;
+                prev[b] = lo32[2ull * max(jc, plane_first + 1u) - 2ull] & CTX_MASK;  // (a plane's first record is a head by its index)
+            }
+#pragma unroll
+            for (uint32_t b = 0; b < 16; b++) {
+                const uint32_t j = wfirst + b * 64u + lane;
+                hm[b] = __ballot(j < st.end && (j == plane_first || cur[b] != prev[b]));
+                count += (uint32_t)__popcll(hm[b]);
+            }
+        }
+        if (lane < 16u) {
+            uint64_t m = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 16; b++) m = lane == b ? hm[b] : m;
+            masks[t][wave][lane] = m;
+        }
+        if (lane == 0) counts[t][wave] = count;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t i = 0; i < HEAD_TILES * (WTHREADS / 64); i++) total += (&counts[0][0])[i];
+        wg_base = total ? atomicAdd(nheads, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t at = wg_base;
+    for (uint32_t t = 0; t < HEAD_TILES; t++) {
+        for (uint32_t w = 0; w < WTHREADS / 64; w++) {
+            const uint32_t c = counts[t][w];
+            if (w == wave && c != 0) {  // (this wave's heads of this tile)
+                SortTile st;
+                (void)sort_tile(meta, nplanes, blockIdx.x * HEAD_TILES + t, st);
+                const uint32_t wfirst = st.begin + wave * 1024u;
+                uint32_t o = at;
+                for (uint32_t b = 0; b < 16; b++) {
+                    const uint64_t m = masks[t][wave][b];
+                    if ((m >> lane) & 1ull) heads[o + mbcnt(m)] = (uint64_t)(wfirst + b * 64u + lane) | ((uint64_t)st.plane << 32);
+                    o += (uint32_t)__popcll(m);
+                }
+            }
+            at += c;
+        }
     }
 }
 
 constexpr int WIDE_NK = 15;             // K_VALUES = 0..=14 (traits.rs:36)
 constexpr uint32_t WIDE_HALVE = 1024;   // COUNT_SCALING (traits.rs:40)
+
+// Four lanes per chain, sixteen chains per wave.  A batch of 4K frames has tens of thousands of chains of a few thousand
+// events each; replaying them event by event, the fifteen counters of a chain spread over four lanes (lane s of the four
+// holds k = s, s + 4, s + 8, s + 12; the sixteenth slot is a dummy that never wins), costs ~30 instructions per event and
+// sixteen chains against the ~500 per 64 events and ONE chain of the wave-wide form below, with no prefix sum in the
+// dependency chain.  What it costs is the latency of the longest chain, so a chain is replayed for `limit` events at most
+// and the rest of it -- position and counters -- handed to the wave-wide kernel (long_heads / long_state / nlong).
+// k of an event = the k of the smallest key S[k] << 4 | (14 - k) (smallest counter, ties to the largest k:
+// parameter_selection.rs:71-85), reduced over the four lanes with two quad permutes; all counters are halved after an
+// event that lifts the smallest above 1024 (:58-68).
+// Memory: the wave works through its chains in chunks of 32 records per chain.  A chunk is loaded a whole chunk ahead
+// (four 16-byte loads per lane), parked in LDS when it is needed, and read from there four records per round; the k bytes of
+// a chunk (lane s of the four keeps event s of every round) wait in LDS too and leave with eight stores right before
+// the next chunk's loads are issued.  So the only wait for memory is the one for a chunk loaded a chunk's time earlier, with
+// no younger store in front of it: vmcnt counts loads and stores in order on gfx9, and with the loads two rounds ahead and
+// a k store per event the kernel ran at the latency of a load per two rounds (0.23 us per event; 0.5 us with the stores).
+// What is left (profiles/r03/quad_stamps.txt): 41 % of a wave's time in the rounds, 44 % in front of the address unit with
+// the eight scattered byte stores and the four loads behind them (a scattered byte costs the chip ~11 ps, the microbenchmark
+// profiles/tools/micro/byte_scatter.hip: 87 M of them per step are 1.0 ms); spreading the stores over the rounds was slower.
+constexpr uint32_t QUAD_ROUND = 4;                                   // events per round: one per lane of the four
+constexpr uint32_t QUAD_CHUNK = 32;                                  // records per chain and chunk
+constexpr uint32_t QUAD_ROUNDS = QUAD_CHUNK / QUAD_ROUND;
+constexpr uint32_t QUAD_STRIDE = QUAD_CHUNK * 2 + 4;                 // dwords per chain in LDS: + 4 spreads the chains over the banks
+constexpr uint32_t QUAD_DUMMY = 1u << 27;                            // the sixteenth counter: above every real one, and S << 4 still fits
+
+__device__ __forceinline__ uint4 load_rec_pair(const uint64_t *p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ uint32_t quad_min(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0xB1, 0xF, 0xF, false));  // quad_perm:[1,0,3,2]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x4E, 0xF, 0xF, false));  // quad_perm:[2,3,0,1]
+    return v;
+}
+
+#ifdef FELICS_QUAD_STAMPS
+// Diagnostic build only: s_memtime ticks of every wave, summed by phase: [0] wait for the chunk + parking it in LDS,
+// [1] the k stores of the chunk before, [2] issuing the next chunk's loads, [3] the rounds, [4] chunks, [5] set-up per group.
+__device__ unsigned long long g_quad_stamps[8];
+#define QSTAMP(i)                                                      \
+    do {                                                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+        qst[i] += now_ - qlast;                                        \
+        qlast = now_;                                                  \
+    } while (0)
+extern "C" __attribute__((visibility("default"))) int felics_debug_quad_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_quad_stamps), sizeof(g_quad_stamps)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_quad_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define QSTAMP(i)
+#endif
+
+__global__ __launch_bounds__(64) void k_wide_chains_quad(const uint64_t *__restrict__ recs, const uint32_t *__restrict__ meta,
+                                                        uint32_t nplanes, uint32_t npix, const uint64_t *__restrict__ heads,
+                                                        const uint32_t *__restrict__ nheads, uint8_t *__restrict__ k_map,
+                                                        uint32_t limit, uint64_t *__restrict__ long_heads,
+                                                        uint32_t *__restrict__ long_state, uint32_t *__restrict__ nlong) {
+    constexpr uint32_t CTX_MASK = (1u << REC_CTX_BITS) - 1u, E_MASK = (1u << REC_E_BITS) - 1u;
+    __shared__ __attribute__((aligned(16))) uint32_t recbuf[16 * QUAD_STRIDE];
+    __shared__ uint2 kbuf[QUAD_ROUNDS][64];  // {where, k} of every lane's event of every round of the chunk
+    const uint32_t lane = lane_id(), sub = lane & 3u, chain = lane >> 2;
+    const uint32_t nchains = *nheads;
+    const uint32_t nrecs = meta[0];         // (the record buffer is readable for 64 records past this)
+    const uint32_t spare = nplanes * npix;  // (k_map is STAGE_PAD bytes longer than the planes)
+    const uint32_t floor3 = sub == 3u ? QUAD_DUMMY : 0u;
+    uint32_t add[4], low[4];  // per event S[i] += (e >> k_i) + 1 + k_i; key_i = S[i] << 4 | 14 - k_i
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+        add[i] = 1u + sub + 4u * i;
+        low[i] = 14u - min(sub + 4u * i, 14u);
+    }
+    uint32_t *const mine = recbuf + chain * QUAD_STRIDE;
+#ifdef FELICS_QUAD_STAMPS
+    unsigned long long qst[8] = {}, qlast = __builtin_amdgcn_s_memtime();
+#endif
+    for (uint32_t g = blockIdx.x; g * 16u < nchains; g += gridDim.x) {
+        const uint32_t c = g * 16u + chain;
+        const bool have = c < nchains;
+        const uint64_t hd = have ? heads[c] : 0ull;
+        const uint32_t j0 = (uint32_t)hd, plane = (uint32_t)(hd >> 32);
+        const uint32_t plane_end = have ? meta[WMETA_EV0 + plane + 1] : 0u;
+        const uint32_t stop = (uint32_t)min((uint64_t)plane_end, (uint64_t)j0 + limit);  // the chain's events here: j0 .. stop - 1 at most
+        const uint32_t ctx = (uint32_t)recs[min(j0, nrecs)] & CTX_MASK;
+        const uint32_t kbase = plane * npix;  // (a pass has fewer than 2^32 samples)
+        uint32_t S[4] = {0u, 0u, 0u, floor3};
+        uint32_t mkey = 0;  // smallest key of the chain's counters: all zero -> k = 14
+        uint32_t j = j0;    // first record of the round in hand
+        bool alive = have;
+        // one event of the chain: counters, smallest key, halving
+        auto event = [&](uint32_t lo_q, uint32_t hi_q) {
+            const uint32_t e = __builtin_amdgcn_alignbit(hi_q, lo_q, REC_CTX_BITS) & E_MASK;
+            uint32_t t = e >> sub;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) {
+                S[i] += t + add[i];  // rice_coding.rs:40-46
+                t >>= 4;
+            }
+            mkey = quad_min(min(min((S[0] << 4) | low[0], (S[1] << 4) | low[1]), min((S[2] << 4) | low[2], (S[3] << 4) | low[3])));
+            const bool halve = mkey >= ((WIDE_HALVE + 1u) << 4);
+            if (__any(halve)) {
+                const uint32_t h = halve ? 1u : 0u;
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) S[i] >>= h;
+                S[3] = max(S[3], floor3);
+                mkey = quad_min(min(min((S[0] << 4) | low[0], (S[1] << 4) | low[1]), min((S[2] << 4) | low[2], (S[3] << 4) | low[3])));
+            }
+        };
+        // the lane's eighth of a chunk: records at .. at + 7 of its chain
+        uint4 R[4];
+        auto fetch = [&](uint32_t at) {
+            const uint64_t *p = recs + min(at + 8u * sub, nrecs);
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) R[i] = load_rec_pair(p + 2u * i);
+        };
+        fetch(j);
+        bool pending = false;  // a chunk's k bytes wait in kbuf
+        QSTAMP(5);
+        while (__any(alive)) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) *(uint4 *)(mine + 16u * sub + 4u * i) = R[i];  // (the wait for the chunk: nothing younger in front)
+            QSTAMP(0);
+            if (pending) {
+#pragma unroll
+                for (uint32_t r = 0; r < QUAD_ROUNDS; r++) {
+                    const uint2 w = kbuf[r][lane];
+#ifdef FELICS_DIAG_NO_K  // timing only (wrong output): the walk without its k stores
+                    if (w.y == 0xFFu)
+#endif
+                    k_map[w.x] = (uint8_t)w.y;
+                }
+            }
+            QSTAMP(1);
+            fetch(j + QUAD_CHUNK);
+            QSTAMP(2);
+            for (uint32_t r = 0; r < QUAD_ROUNDS; r++) {
+                const uint4 r0 = *(const uint4 *)(mine + 8u * r), r1 = *(const uint4 *)(mine + 8u * r + 4u);
+                const uint32_t my_hi = mine[8u * r + 2u * sub + 1u];
+                const uint32_t lo[QUAD_ROUND] = {r0.x, r0.z, r1.x, r1.z}, hi[QUAD_ROUND] = {r0.y, r0.w, r1.y, r1.w};
+                uint32_t my_at = spare, my_k = 0;
+                // the records are sorted by context: the round lies inside the chain if its last record does
+                const bool full = alive && j + (QUAD_ROUND - 1u) < stop && (lo[QUAD_ROUND - 1u] & CTX_MASK) == ctx;
+                if (__all(full || !alive)) {
+                    if (alive) {
+#pragma unroll
+                        for (uint32_t q = 0; q < QUAD_ROUND; q++) {
+                            my_k = sub == q ? mkey : my_k;
+                            event(lo[q], hi[q]);
+                        }
+                        my_at = kbase + (my_hi >> (REC_CTX_BITS + REC_E_BITS - 32u));
+                    }
+                } else {  // a chain of the wave ends in this round
+#pragma unroll
+                    for (uint32_t q = 0; q < QUAD_ROUND; q++) {
+                        alive = alive && j + q < stop && (lo[q] & CTX_MASK) == ctx;
+                        if (alive) {
+                            if (sub == q) my_k = mkey, my_at = kbase + (my_hi >> (REC_CTX_BITS + REC_E_BITS - 32u));
+                            event(lo[q], hi[q]);
+                        }
+                    }
+                }
+                kbuf[r][lane] = make_uint2(my_at, 14u - (my_k & 15u));
+                j += QUAD_ROUND;
+            }
+            pending = true;
+            QSTAMP(3);
+#ifdef FELICS_QUAD_STAMPS
+            qst[4]++;
+#endif
+        }
+        if (pending) {
+#pragma unroll
+            for (uint32_t r = 0; r < QUAD_ROUNDS; r++) {
+                const uint2 w = kbuf[r][lane];
+#ifdef FELICS_DIAG_NO_K
+                if (w.y == 0xFFu)
+#endif
+                k_map[w.x] = (uint8_t)w.y;
+            }
+        }
+        // a chain that goes on behind its last event here: the records are sorted by context inside the plane, so it does if
+        // the record at `stop` is of this plane and this context
+        const bool more = have && stop < plane_end && ((uint32_t)recs[min(stop, nrecs)] & CTX_MASK) == ctx;
+        uint32_t at = 0;
+        if (more && sub == 0u) at = atomicAdd(nlong, 1u);
+        at = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)at, 0x00, 0xF, 0xF, false);  // quad_perm:[0,0,0,0]: the four lanes' slot
+        if (more) {
+            if (sub == 0u) long_heads[at] = (uint64_t)stop | ((uint64_t)plane << 32);
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++)
+                if (sub + 4u * i < (uint32_t)WIDE_NK) long_state[(uint64_t)at * 16u + sub + 4u * i] = S[i];
+        }
+        QSTAMP(5);
+    }
+#ifdef FELICS_QUAD_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 6; i++) atomicAdd(&g_quad_stamps[i], qst[i]);
+#endif
+}
 
 // One wave per chain (persistent grid).  Lane l of a step holds event j + l of the chain.  For every
 // Rice parameter the lanes' code lengths are prefix-summed, which gives each lane the counters as
@@ -359,7 +616,8 @@ constexpr uint32_t WIDE_HALVE = 1024;   // COUNT_SCALING (traits.rs:40)
 // The next block's records are in flight while this one is resolved.
 __global__ __launch_bounds__(256) void k_wide_chains(const uint64_t *__restrict__ recs, const uint32_t *__restrict__ meta,
                                                      uint32_t nplanes, uint32_t npix, const uint64_t *__restrict__ heads,
-                                                     const uint32_t *__restrict__ nheads, uint8_t *__restrict__ k_map) {
+                                                     const uint32_t *__restrict__ nheads, const uint32_t *__restrict__ resume,
+                                                     uint8_t *__restrict__ k_map) {
     const uint32_t lane = lane_id();
     const uint32_t nchains = *nheads;
     const uint32_t wave0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -371,9 +629,10 @@ __global__ __launch_bounds__(256) void k_wide_chains(const uint64_t *__restrict_
         const uint32_t plane_end = meta[WMETA_EV0 + plane + 1];
         uint8_t *kp = k_map + (uint64_t)plane * npix;
         const uint32_t ctx = rec_ctx(recs[j]);
-        uint32_t S[WIDE_NK];
+        uint32_t S[WIDE_NK];  // (resume: the counters k_wide_chains_quad left, 16 words per chain)
 #pragma unroll
-        for (int k = 0; k < WIDE_NK; k++) S[k] = 0;
+        for (int k = 0; k < WIDE_NK; k++)
+            S[k] = resume ? (uint32_t)__builtin_amdgcn_readfirstlane((int)resume[(uint64_t)c * 16u + (uint32_t)k]) : 0u;
         // Records are streamed two blocks ahead with unconditional loads (index clamped to the plane's last record) and k
         // leaves with an unconditional store (lanes without an event write a spare byte behind the planes): no branch around
         // a memory operation, so the wait for a block's records is a counted one that leaves the younger operations -- the
@@ -462,7 +721,7 @@ WideSizes wide_sizes(const Geometry &g) {
     z.max_sort_tiles = (uint32_t)(nsamples / WT + g.nplanes);
     z.tile_cnt_bytes = (size_t)z.px_tiles * g.nplanes * 4;
     z.meta_bytes = (size_t)(WMETA_EV0 + 2 * (g.nplanes + 1)) * 4;
-    z.rec_bytes = (size_t)nsamples * 8 + 64;
+    z.rec_bytes = (size_t)nsamples * 8 + 512;  // (k_wide_chains_quad reads up to 39 records past the last)
     z.hist_bytes = (size_t)z.max_sort_tiles * WDIG * 4;
     z.heads_bytes = (size_t)nsamples * 8 + 64;
     z.digtot_bytes = (size_t)g.nplanes * WDIG * 4;
@@ -493,12 +752,37 @@ void launch_wide_sort(hipStream_t s, uint64_t *recs_a, uint64_t *recs_b, const u
     }
 }
 
-void launch_wide_chains(hipStream_t s, const uint64_t *recs, const uint32_t *meta, uint64_t *heads, uint32_t *nheads,
-                        uint8_t *k_map, const Geometry &g) {
+void launch_wide_chains(hipStream_t s, const uint64_t *recs, const uint32_t *meta, uint64_t *heads, uint32_t *counters,
+                        uint8_t *k_map, const Geometry &g, uint32_t lane_limit, uint64_t *long_heads, uint32_t *long_state) {
     const WideSizes z = wide_sizes(g);
-    FELICS_LAUNCH(k_wide_heads, dim3(z.max_sort_tiles), dim3(WTHREADS), s, recs, meta, g.nplanes, heads, nheads);
+    uint32_t *nheads = counters, *nlong = counters + 1;
+    FELICS_LAUNCH(k_wide_heads, dim3(cdiv(z.max_sort_tiles, HEAD_TILES)), dim3(WTHREADS), s, recs, meta, g.nplanes, heads, nheads);
+    if (lane_limit != 0) {
+        // four lanes per chain up to lane_limit events of it (persistent: eight waves per SIMD at most), the wave-wide kernel
+        // for what is left of longer chains
+        FELICS_LAUNCH(k_wide_chains_quad, dim3(256u * 32u), dim3(64), s, recs, meta, g.nplanes, g.npix, heads, nheads, k_map, lane_limit,
+                      long_heads, long_state, nlong);
+        FELICS_LAUNCH(k_wide_chains, dim3(256u * 8u), dim3(256), s, recs, meta, g.nplanes, g.npix, long_heads, nlong,
+                      (const uint32_t *)long_state, k_map);
+        return;
+    }
     // persistent: 8 workgroups of 4 waves per CU share the chains
-    FELICS_LAUNCH(k_wide_chains, dim3(256u * 8u), dim3(256), s, recs, meta, g.nplanes, g.npix, heads, nheads, k_map);
+    FELICS_LAUNCH(k_wide_chains, dim3(256u * 8u), dim3(256), s, recs, meta, g.nplanes, g.npix, heads, nheads,
+                  (const uint32_t *)nullptr, k_map);
+}
+
+// How many events of a chain one lane replays before the wave-wide kernel takes over (0: the wave-wide kernel does everything).
+// The four-lane form needs ~0.3 us per event of the longest chain whatever the batch; the wave-wide kernel gets through a batch
+// at ~2 ns per 64 events.  So the four-lane form pays when the batch is large enough for the chip to be busy with whole chains
+// (profiles/r03/wide_chains_sweep.txt).
+uint32_t wide_lane_limit(const Geometry &g) {
+    const uint64_t nsamples = (uint64_t)g.nplanes * g.npix;
+    if (nsamples < WIDE_LANE_MIN_SAMPLES) return 0;
+    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(nsamples / 8192u, WIDE_LANE_LIMIT_MIN), WIDE_LANE_LIMIT_MAX);
+}
+// chains longer than the limit: fewer than nsamples / limit of them (+ one per plane for the rounding)
+size_t wide_long_capacity(const Geometry &g, uint32_t lane_limit) {
+    return lane_limit ? (size_t)((uint64_t)g.nplanes * g.npix / lane_limit + g.nplanes + 1) : 0;
 }
 
 }  // namespace felics

@@ -298,6 +298,47 @@ def test_pack_variants(oracle):
             e.close()
 
 
+def test_sixteen_bit_lane_replay(oracle):
+    """16-bit samples: a large batch replays every chain on four lanes (k_wide_chains_quad) up to a limit of events and hands
+    the rest of a longer chain -- position and counters -- to the wave-per-chain kernel.  FELICS_WIDE_LANE forces the
+    limit on small inputs: hand-over after 1, 7, 64 events and never, against the wave-per-chain kernel alone (0)."""
+    import felics_amd
+    from felics_amd import synth
+
+    rng = np.random.default_rng(5)
+    frames = [synth.gray16(640, 360, f) for f in range(3)]
+    frames.append(rng.integers(0, 65536, size=(97, 131), dtype=np.uint16))                 # noise: k = 14 territory
+    frames.append((np.arange(200 * 300).reshape(200, 300) % 7).astype(np.uint16))          # few contexts, long chains
+    flat = np.full((64, 64), 40000, dtype=np.uint16)
+    flat[::9, ::5] = 3                                                                      # full-scale spikes
+    frames.append(flat)
+    rgb = [np.stack([synth.gray16(320, 200, f), synth.gray16(320, 200, f + 9), synth.gray16(320, 200, f + 5) // 3], -1) for f in range(2)]
+    want = [oracle.compress(f) for f in frames]
+    want_rgb = [oracle.compress(f) for f in rgb]
+    for limit in ("0", "1", "7", "64", "1000000"):
+        os.environ["FELICS_WIDE_LANE"] = limit
+        os.environ["FELICS_POISON"] = "1"
+        try:
+            e = felics_amd.Encoder(0)
+            try:
+                for f, w in zip(frames, want):
+                    assert e.compress_batch([f]) == [w], (limit, f.shape)
+                same = [frames[0], frames[1], frames[2]]
+                assert e.compress_batch(same) == want[:3], limit
+                assert e.compress_batch(rgb) == want_rgb, limit
+            finally:
+                e.close()
+        finally:
+            del os.environ["FELICS_WIDE_LANE"], os.environ["FELICS_POISON"]
+    # the limit the library chooses by itself: thirteen 4K frames are enough for the four-lane form
+    big = [synth.gray16(3840, 2160, f % 5) for f in range(13)]
+    e = felics_amd.Encoder(0)
+    try:
+        assert e.compress_batch(big) == [oracle.compress(f) for f in big]
+    finally:
+        e.close()
+
+
 def test_random_shapes_and_contents(enc, oracle):
     """A few seconds of random geometry (1 pixel wide to 5000), content (noise, ramps, flat with full-scale
     spikes, constant), sample type and batch size, every stream compared with the oracle."""

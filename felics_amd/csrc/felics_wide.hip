@@ -180,11 +180,17 @@ __global__ __launch_bounds__(WTHREADS) void k_wide_emit(const T *__restrict__ pl
             if (q == j) mine[q] = make_rec(pc.ctx, pc.val, i);
         n++;
     });
+    // the tile's records are lined up in LDS and leave from there, neighbouring lanes writing neighbouring records (straight
+    // from the registers a store touched ~40 lines: a thread's events are ~10 records away from its neighbour's)
+    __shared__ uint64_t lined[WT];
     uint32_t total;
-    uint32_t at = tile_base[blockIdx.y * gridDim.x + blockIdx.x] + block_excl_scan(n, wsum, &total);
+    uint32_t at = block_excl_scan(n, wsum, &total);
 #pragma unroll
     for (uint32_t j = 0; j < 16u; j++)
-        if (mine[j] != ~0ull) recs[at++] = mine[j];
+        if (mine[j] != ~0ull) lined[at++] = mine[j];
+    __syncthreads();
+    uint64_t *out = recs + tile_base[blockIdx.y * gridDim.x + blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < total; i += WTHREADS) out[i] = lined[i];
 }
 
 // Which plane a sort tile belongs to, and its record range.
@@ -207,22 +213,67 @@ __device__ __forceinline__ bool sort_tile(const uint32_t *__restrict__ meta, uin
     return true;
 }
 
-// histogram of one digit per sort tile: hist[(WDIG * stile_first[plane]) + digit * ntile + t]
+// One count per record into an LDS histogram.  The high digit of the contexts is the same for almost every record of a tile
+// (64 lanes adding to ONE LDS word take 64 turns): the lanes that share the first lane's digit are counted with one add.
+__device__ __forceinline__ void count_digit(uint32_t *h, uint32_t d, bool valid) {
+    const uint64_t vm = __ballot(valid);
+    if (vm == 0) return;
+    const uint32_t d0 = readlane(d, (uint32_t)__builtin_ctzll(vm));
+    const uint64_t same = __ballot(valid && d == d0);
+    if (__popcll(same) >= 8) {
+        if (lane_id() == (uint32_t)__builtin_ctzll(same)) atomicAdd(&h[d0], (uint32_t)__popcll(same));
+        valid = valid && d != d0;
+    }
+    if (valid) atomicAdd(&h[d], 1u);
+}
+
+// histogram of one digit per sort tile: hist[(WDIG * stile_first[plane]) + digit * ntile + t].  A workgroup counts
+// HIST_TILES consecutive tiles: their counts of a digit are neighbours in the matrix and leave with one store, and the
+// digit's total of the plane gets one atomic for all of them (one tile per workgroup meant 512 scattered dword stores
+// and up to 512 atomics per 4096 records: the kernel waited for its address unit, not for the records).
+constexpr uint32_t HIST_TILES = 4;
 __global__ __launch_bounds__(WTHREADS) void k_wsort_hist(const uint64_t *__restrict__ recs, const uint32_t *__restrict__ meta,
                                                          uint32_t nplanes, uint32_t shift, uint32_t *__restrict__ hist,
                                                          uint32_t *__restrict__ dig_tot) {
-    __shared__ uint32_t h[WDIG];
-    SortTile st;
-    if (!sort_tile(meta, nplanes, blockIdx.x, st)) return;
-    for (uint32_t d = threadIdx.x; d < WDIG; d += WTHREADS) h[d] = 0;
+    __shared__ uint32_t h[HIST_TILES][WDIG];
+    SortTile st[HIST_TILES];
+    bool have[HIST_TILES];
+    for (uint32_t d = threadIdx.x; d < HIST_TILES * WDIG; d += WTHREADS) (&h[0][0])[d] = 0;
     __syncthreads();
-    for (uint32_t j = st.begin + threadIdx.x; j < st.end; j += WTHREADS) atomicAdd(&h[(rec_ctx(recs[j]) >> shift) & (WDIG - 1u)], 1u);
+#pragma unroll
+    for (uint32_t i = 0; i < HIST_TILES; i++) {
+        have[i] = sort_tile(meta, nplanes, blockIdx.x * HIST_TILES + i, st[i]);
+        if (!have[i]) continue;
+        uint64_t r[WT / WTHREADS];
+#pragma unroll
+        for (uint32_t k = 0; k < WT / WTHREADS; k++) {
+            const uint32_t j = st[i].begin + k * WTHREADS + threadIdx.x;
+            r[k] = j < st[i].end ? recs[j] : ~0ull;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < WT / WTHREADS; k++)
+            count_digit(h[i], (rec_ctx(r[k]) >> shift) & (WDIG - 1u), st[i].begin + k * WTHREADS + threadIdx.x < st[i].end);
+    }
     __syncthreads();
+    if (!have[0]) return;
     const uint32_t *stile_first = meta + WMETA_EV0 + nplanes + 1;
-    uint32_t *dst = hist + (uint64_t)WDIG * stile_first[st.plane];
+    const bool one_plane = have[HIST_TILES - 1] && st[HIST_TILES - 1].plane == st[0].plane;
     for (uint32_t d = threadIdx.x; d < WDIG; d += WTHREADS) {
-        dst[(uint64_t)d * st.ntile + st.t] = h[d];
-        if (h[d]) atomicAdd(&dig_tot[st.plane * WDIG + d], h[d]);  // per (plane, digit): lets the scan start anywhere
+        if (one_plane) {  // (the common case: four neighbouring counts, one total)
+            uint32_t *dst = hist + (uint64_t)WDIG * stile_first[st[0].plane] + (uint64_t)d * st[0].ntile + st[0].t;
+            uint32_t v[HIST_TILES], sum = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < HIST_TILES; i++) v[i] = h[i][d], sum += v[i];
+            __builtin_memcpy(dst, v, sizeof v);
+            if (sum) atomicAdd(&dig_tot[st[0].plane * WDIG + d], sum);  // per (plane, digit): lets the scan start anywhere
+            continue;
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < HIST_TILES; i++) {
+            if (!have[i]) continue;
+            hist[(uint64_t)WDIG * stile_first[st[i].plane] + (uint64_t)d * st[i].ntile + st[i].t] = h[i][d];
+            if (h[i][d]) atomicAdd(&dig_tot[st[i].plane * WDIG + d], h[i][d]);
+        }
     }
 }
 
@@ -269,11 +320,21 @@ __global__ __launch_bounds__(1024) void k_wsort_scan(uint32_t *__restrict__ hist
 }
 
 // Stable scatter of one digit.  Wave w of a tile owns records [w * 1024, (w + 1) * 1024) of it, 64 at a time in
-// order; the lanes that share a digit rank themselves with one ballot per digit bit.
+// order; the lanes that share a digit rank themselves with one ballot per digit bit.  The tile is put in digit order in
+// LDS first and written from there, so that neighbouring lanes write neighbouring records: with 512 digits a tile has runs
+// of ~8 records per digit, and written straight from the ranking every record was a partial line of its own (the first
+// pass took three times as long as the second, which has a handful of digits).
+// (REORDER = false: written straight from the ranking -- the second pass, whose digits are the high context bits: 0.35 ms
+// against 0.60 through LDS, which then only costs occupancy.)
+template <bool REORDER>
 __global__ __launch_bounds__(WTHREADS) void k_wsort_scatter(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst,
                                                             const uint32_t *__restrict__ meta, uint32_t nplanes, uint32_t shift,
                                                             const uint32_t *__restrict__ hist) {
-    __shared__ uint32_t run[WTHREADS / 64][WDIG];
+    __shared__ uint32_t run[WTHREADS / 64][WDIG];  // per wave and digit: count, then the place (in the tile / in dst) of the wave's next record of it
+    __shared__ uint32_t gbase[REORDER ? WDIG : 1];  // where the tile's records of a digit go, minus their place in the tile
+    __shared__ uint64_t sorted[REORDER ? WT : 1];   // the tile in digit order
+    __shared__ uint32_t wsum[WTHREADS / 64];
+    static_assert(WDIG == 2 * WTHREADS, "a thread scans two digits");
     SortTile st;
     if (!sort_tile(meta, nplanes, blockIdx.x, st)) return;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
@@ -286,18 +347,37 @@ __global__ __launch_bounds__(WTHREADS) void k_wsort_scatter(const uint64_t *__re
     for (uint32_t b = 0; b < 16; b++) {
         const uint32_t j = wfirst + b * 64u + lane;
         rec[b] = j < st.end ? src[j] : ~0ull;
-        if (j < st.end) atomicAdd(&run[wave][(rec_ctx(rec[b]) >> shift) & (WDIG - 1u)], 1u);
     }
+#pragma unroll
+    for (uint32_t b = 0; b < 16; b++) count_digit(run[wave], (rec_ctx(rec[b]) >> shift) & (WDIG - 1u), wfirst + b * 64u + lane < st.end);
     __syncthreads();
-    // counts -> where each wave's records of each digit go
     const uint32_t *stile_first = meta + WMETA_EV0 + nplanes + 1;
     const uint32_t *off = hist + (uint64_t)WDIG * stile_first[st.plane];
-    for (uint32_t d = threadIdx.x; d < WDIG; d += WTHREADS) {
-        uint32_t at = off[(uint64_t)d * st.ntile + st.t];
-        for (uint32_t w = 0; w < WTHREADS / 64; w++) {
-            const uint32_t c = run[w][d];
-            run[w][d] = at;
-            at += c;
+    if (!REORDER) {  // counts -> where each wave's records of each digit go
+        for (uint32_t d = threadIdx.x; d < WDIG; d += WTHREADS) {
+            uint32_t at = off[(uint64_t)d * st.ntile + st.t];
+            for (uint32_t w = 0; w < WTHREADS / 64; w++) {
+                const uint32_t n = run[w][d];
+                run[w][d] = at;
+                at += n;
+            }
+        }
+    } else {  // counts -> the place in the tile of each wave's records of each digit (digit-major, then wave), and where the digit goes
+        const uint32_t d0 = 2u * threadIdx.x;
+        uint32_t c[2] = {0u, 0u};
+#pragma unroll
+        for (uint32_t i = 0; i < 2; i++)
+            for (uint32_t w = 0; w < WTHREADS / 64; w++) c[i] += run[w][d0 + i];
+        uint32_t total;
+        uint32_t at = block_excl_scan(c[0] + c[1], wsum, &total);
+#pragma unroll
+        for (uint32_t i = 0; i < 2; i++) {
+            gbase[d0 + i] = off[(uint64_t)(d0 + i) * st.ntile + st.t] - at;
+            for (uint32_t w = 0; w < WTHREADS / 64; w++) {
+                const uint32_t n = run[w][d0 + i];
+                run[w][d0 + i] = at;
+                at += n;
+            }
         }
     }
     __syncthreads();
@@ -318,12 +398,25 @@ __global__ __launch_bounds__(WTHREADS) void k_wsort_scatter(const uint64_t *__re
         }
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
         const uint32_t group = (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);
-        uint32_t dest = 0;
-        if (ev) dest = myrun[d] + rank;
+        uint32_t place = 0;
+        if (ev) place = myrun[d] + rank;
         __builtin_amdgcn_wave_barrier();
-        if (ev && rank == 0) myrun[d] = dest + group;
+        if (ev && rank == 0) myrun[d] = place + group;
         __builtin_amdgcn_wave_barrier();
-        if (ev) dst[dest] = rec[b];
+        if (ev) {
+            if (REORDER) sorted[place] = rec[b]; else dst[place] = rec[b];
+        }
+    }
+    if (!REORDER) return;
+    __syncthreads();
+    const uint32_t n = st.end - st.begin;
+#pragma unroll
+    for (uint32_t k = 0; k < WT / WTHREADS; k++) {
+        const uint32_t place = k * WTHREADS + threadIdx.x;
+        if (place < n) {
+            const uint64_t r = sorted[place];
+            dst[gbase[(rec_ctx(r) >> shift) & (WDIG - 1u)] + place] = r;
+        }
     }
 }
 
@@ -745,9 +838,12 @@ void launch_wide_sort(hipStream_t s, uint64_t *recs_a, uint64_t *recs_b, const u
     uint64_t *src = recs_a, *dst = recs_b;
     for (uint32_t shift = 0; shift < REC_CTX_BITS; shift += 9) {
         (void)hipMemsetAsync(dig_tot, 0, z.digtot_bytes, s);
-        FELICS_LAUNCH(k_wsort_hist, dim3(z.max_sort_tiles), dim3(WTHREADS), s, src, meta, g.nplanes, shift, hist, dig_tot);
+        FELICS_LAUNCH(k_wsort_hist, dim3(cdiv(z.max_sort_tiles, HIST_TILES)), dim3(WTHREADS), s, src, meta, g.nplanes, shift, hist, dig_tot);
         FELICS_LAUNCH(k_wsort_scan, dim3(WDIG / WSCAN_DIGITS, g.nplanes), dim3(1024), s, hist, meta, g.nplanes, dig_tot);
-        FELICS_LAUNCH(k_wsort_scatter, dim3(z.max_sort_tiles), dim3(WTHREADS), s, src, dst, meta, g.nplanes, shift, hist);
+        if (shift == 0)
+            FELICS_LAUNCH(k_wsort_scatter<true>, dim3(z.max_sort_tiles), dim3(WTHREADS), s, src, dst, meta, g.nplanes, shift, hist);
+        else
+            FELICS_LAUNCH(k_wsort_scatter<false>, dim3(z.max_sort_tiles), dim3(WTHREADS), s, src, dst, meta, g.nplanes, shift, hist);
         std::swap(src, dst);
     }
 }

@@ -398,8 +398,10 @@ def main():
                     traffic = int(t / launches) if t else None
                     insts = tj.get("_valu_wave_insts_per_step")
                     if insts:  # wave64 VALU instructions per step against 1024 SIMDs x 2.4 GHz / 2 cycles per instruction
-                        valu = {"wave_insts_per_step": int(insts), "issue_peak_per_s": 1.2288e12,
-                                "frac_of_issue_peak": round(insts / 1.2288e12 / (ms_per_step * 1e-3), 4)}
+                        # the chip's sustained rate of wave64 integer VALU instructions, measured (profiles/tools/micro/valu_rate.hip,
+                        # profiles/r03/valu_rate.txt: 1.71-1.73 ns per instruction and SIMD with every SIMD issuing), not a data-sheet figure
+                        valu = {"wave_insts_per_step": int(insts), "issue_peak_per_s": 0.595e12, "issue_peak": "measured, profiles/r03/valu_rate.txt",
+                                "frac_of_issue_peak": round(insts / 0.595e12 / (ms_per_step * 1e-3), 4)}
             roofline = {"bound": "hbm", "kernel": kernel_of(dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(per_launch_ms, 4),

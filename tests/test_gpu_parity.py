@@ -373,6 +373,50 @@ def test_random_shapes_and_contents(enc, oracle):
     assert batches > 20
 
 
+def test_sixteen_bit_lane_replay_random_shapes(oracle):
+    """The four-lane chain kernel and its hand-over on random geometry: 16-bit gray and RGB frames from 1 pixel wide to a few
+    thousand, noise / ramps / spikes / constant, batches of 1-6 frames, with the chain limit forced to 3 events, then to 50
+    (FELICS_WIDE_LANE; the library itself only takes this path for batches of ~100 M samples)."""
+    import time
+    import felics_amd
+
+    rng = np.random.default_rng(1234)
+
+    def content(h, w, c, kind):
+        shape = (h, w) if c == 1 else (h, w, 3)
+        if kind == 0:
+            return rng.integers(0, 65536, size=shape).astype(np.uint16)
+        if kind == 1:
+            base = np.add.outer(np.arange(h) * 5, np.arange(w) * 3) % 65536
+            img = base if c == 1 else np.stack([base, base[::-1], (base * 7) % 65536], -1)
+            return (img + rng.integers(0, 9, size=shape)).clip(0, 65535).astype(np.uint16)
+        if kind == 2:
+            img = np.full(shape, 21000, dtype=np.int64) + rng.integers(0, 3, size=shape)
+            n = max(1, h * w // 40)
+            img[rng.integers(0, h, n), rng.integers(0, w, n)] = rng.choice([0, 65535], size=(n,) if c == 1 else (n, 3))
+            return img.astype(np.uint16)
+        return np.full(shape, rng.integers(0, 65536), dtype=np.uint16)
+
+    for limit in ("3", "50"):
+        os.environ["FELICS_WIDE_LANE"] = limit
+        try:
+            e = felics_amd.Encoder(0)
+            try:
+                t0, batches = time.time(), 0
+                while time.time() - t0 < 4.0:
+                    w = int(rng.choice([rng.integers(1, 40), rng.integers(1, 700), rng.integers(1000, 3000)]))
+                    h = int(rng.choice([rng.integers(1, 40), rng.integers(1, 200)]))
+                    c = int(rng.choice([1, 3]))
+                    frames = [content(h, w, c, int(rng.integers(0, 4))) for _ in range(int(rng.integers(1, 7)))]
+                    assert e.compress_batch(frames) == [oracle.compress(f) for f in frames], (limit, w, h, c, len(frames))
+                    batches += 1
+                assert batches > 8
+            finally:
+                e.close()
+        finally:
+            del os.environ["FELICS_WIDE_LANE"]
+
+
 def test_several_passes(oracle):
     """A batch larger than one pass holds (FELICS_TEST_PASS_IMAGES caps the pass instead of a 400-frame 4K
     batch): host-pointer and device entry points, gray / RGB / 16-bit."""

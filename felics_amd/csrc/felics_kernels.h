@@ -245,7 +245,7 @@ void launch_wide_sort(hipStream_t s, uint64_t *recs_a, uint64_t *recs_b, const u
 // handed over}: two words, zero beforehand.  lane_limit != 0: four lanes per chain for its first lane_limit events
 // (k_wide_chains_quad), the wave-per-chain kernel for the rest (long_heads: 8 bytes, long_state: 64 bytes per chain handed
 // over, wide_long_capacity() of them); lane_limit == 0: the wave-per-chain kernel alone.
-constexpr uint32_t WIDE_LANE_LIMIT_MIN = 4096, WIDE_LANE_LIMIT_MAX = 16384;
+constexpr uint32_t WIDE_LANE_LIMIT_MIN = 2048, WIDE_LANE_LIMIT_MAX = 4096;
 constexpr uint64_t WIDE_LANE_MIN_SAMPLES = 96u << 20;  // (measured: 8 4K planes 1.28 against 1.49 ms for the wave-wide form, 16: 2.74 against 2.31, 32: 5.40 against 3.60)
 uint32_t wide_lane_limit(const Geometry &g);
 size_t wide_long_capacity(const Geometry &g, uint32_t lane_limit);

@@ -874,7 +874,10 @@ void launch_wide_chains(hipStream_t s, const uint64_t *recs, const uint32_t *met
 uint32_t wide_lane_limit(const Geometry &g) {
     const uint64_t nsamples = (uint64_t)g.nplanes * g.npix;
     if (nsamples < WIDE_LANE_MIN_SAMPLES) return 0;
-    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(nsamples / 8192u, WIDE_LANE_LIMIT_MIN), WIDE_LANE_LIMIT_MAX);
+    // (a chain costs the four-lane kernel ~0.3 us per event however long the others are: with a limit of 16 000 events a batch
+    // of height maps, whose smallest contexts hold chains of 100 000 events, took 5.4 ms against 4.3 for the wave-wide kernel
+    // alone, a natural-like batch 7.2 against 6.9 -- and 5.9 with the limit at 2 000-4 000; profiles/r03/content16.txt)
+    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(nsamples / 32768u, WIDE_LANE_LIMIT_MIN), WIDE_LANE_LIMIT_MAX);
 }
 // chains longer than the limit: fewer than nsamples / limit of them (+ one per plane for the rounding)
 size_t wide_long_capacity(const Geometry &g, uint32_t lane_limit) {

@@ -450,8 +450,8 @@ def main():
                                    % (F, "S1-RGB" if args.rgb else args.kind, W, H, 16 if args.depth16 else 8,
                                       "RGB" if args.rgb else "grayscale"),
                        "content": {"S1": "S1 natural-like synthetic (BASELINE.md section 2): smooth ramps + 3 bits of noise, ~3.6 bits per pixel; "
-                                         "the figure holds for this content only -- S2 noise frames took 3.6x the time per step, "
-                                         "natural-like photographs 1.3-1.4x (profiles/r02/content_sensitivity.txt)",
+                                         "the figure holds for this content only -- S2 noise frames take 3.5x the time per step, "
+                                         "natural-like frames (texture of varying strength, sharp edges) 1.1x (profiles/r03/content_sensitivity.txt)",
                                    "S2": "S2 uniform noise (worst case)", "S3": "S3 flat (best case)"}[args.kind],
                        "baseline_config": args.config, "frames_per_gpu": F, "width": W, "height": H, "channels": channels,
                        "sharding": "frames split across ranks, no collective"},

@@ -746,25 +746,26 @@ __global__ __launch_bounds__(256) void k_wide_chains(const uint64_t *__restrict_
             const uint32_t e = valid ? rec_e(mine) : 0u;
             // One set of prefix sums per block; a halving at lane f turns the counters into ((S + P(f)) >> 1) - P(f), to which the
             // lanes behind f add their own P(t) >= P(f) again (mod 2^32) -- no second scan.
-            uint32_t P[WIDE_NK], len[WIDE_NK];
+            // The counters before a lane's event are S + (P - len): as keys ((P - len) << 4 | 14 - k) + (S << 4), whose minimum over k
+            // names the smallest counter with ties to the largest k -- one add per counter and round instead of add, subtract,
+            // compare and two selects (the part in brackets does not change when the counters are halved).
+            uint32_t P[WIDE_NK], keyB[WIDE_NK];
 #pragma unroll
             for (int k = 0; k < WIDE_NK; k++) {
-                len[k] = valid ? (e >> k) + 1u + (uint32_t)k : 0u;  // rice_coding.rs:40-46
-                P[k] = wave_incl_scan(len[k]);
+                const uint32_t len = valid ? (e >> k) + 1u + (uint32_t)k : 0u;  // rice_coding.rs:40-46
+                P[k] = wave_incl_scan(len);
+                keyB[k] = ((P[k] - len) << 4) | (uint32_t)(14 - k);
             }
             uint32_t base = 0;  // first event of the block not yet resolved
             uint32_t my_k = 0;
             while (true) {
-                uint32_t best_k = 0, best = 0xFFFFFFFFu, after_min = 0xFFFFFFFFu;
+                uint32_t key_min = 0xFFFFFFFFu, after_min = 0xFFFFFFFFu;
 #pragma unroll
                 for (int k = 0; k < WIDE_NK; k++) {
-                    const uint32_t after = S[k] + P[k], before = after - len[k];
-                    if (before <= best) {
-                        best = before;
-                        best_k = (uint32_t)k;
-                    }
-                    after_min = min(after_min, after);
+                    key_min = min(key_min, (S[k] << 4) + keyB[k]);  // (mod 2^32: S may have wrapped, S + P - len has not)
+                    after_min = min(after_min, S[k] + P[k]);
                 }
+                const uint32_t best_k = 14u - (key_min & 15u);
                 const bool live = valid && lane >= base;
                 const uint64_t hm = __ballot(live && after_min > WIDE_HALVE);
                 const uint32_t f = hm ? (uint32_t)__builtin_ctzll(hm) : nvalid - 1u;  // last event served by these counters

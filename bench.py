@@ -159,14 +159,11 @@ def main():
             f = first_frame + i
             frames[i] = synth_torch.rgb8(W, H, f, device=dev) if args.rgb else synth_torch.gray8(W, H, f, args.kind, device=dev)
     out_cap = int(F * npix * channels * sample_bytes * 1.25) + (1 << 20)
-    from felics_amd import api as fapi
-
-    depth_q = max(1, int(fapi.lib().felics_lane_count()))  # batches that can be in flight
+    enc = felics_amd.Encoder(local)
+    depth_q = max(1, enc.lane_count())  # batches that can be in flight on this context
     d_outs = [torch.empty(out_cap, dtype=torch.uint8, device=dev) for _ in range(depth_q)]
     d_out = d_outs[0]
     torch.cuda.synchronize()
-
-    enc = felics_amd.Encoder(local)
     color = 1 if args.rgb else 0
 
     depth = 1 if args.depth16 else 0

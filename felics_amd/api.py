@@ -60,7 +60,7 @@ class _CHeader(C.Structure):
 
 
 class _CStats(C.Structure):
-    _fields_ = [("submissions", C.c_uint64), ("fused_submissions", C.c_uint64), ("slot_overflows", C.c_uint64), ("lookback_fallbacks", C.c_uint64),
+    _fields_ = [("submissions", C.c_uint64), ("ticket_retries", C.c_uint64), ("slot_overflows", C.c_uint64), ("lookback_fallbacks", C.c_uint64),
                 ("two_pass", C.c_int), ("failed", C.c_int)]
 
 
@@ -85,7 +85,7 @@ EXPORTS = [
     "felics_read_header", "felics_write_header",
     "felics_decompress", "felics_strerror", "felics_last_error", "felics_set_profiling",
     "felics_stage_count", "felics_stage_name", "felics_get_stage_ms", "felics_get_stage_launches",
-    "felics_lane_count", "felics_get_span_ms", "felics_decompress_with_header", "felics_get_stats", "felics_decompress_batch_device",
+    "felics_lane_count", "felics_ctx_lane_count", "felics_get_span_ms", "felics_decompress_with_header", "felics_get_stats", "felics_decompress_batch_device",
 ]
 
 _lib = None
@@ -150,6 +150,7 @@ def lib():
     L.felics_get_stage_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.felics_get_span_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.felics_get_stage_launches.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
+    L.felics_ctx_lane_count.argtypes = [vp]
     _lib = L
     return L
 
@@ -285,6 +286,10 @@ class Encoder:
         if rc != 0:
             self._raise(rc)
         return Header(ch.color_type, ch.pixel_depth, ch.width, ch.height), status
+
+    def lane_count(self):
+        """felics_ctx_lane_count: submissions this context can have in flight (fixed when it was created)."""
+        return int(lib().felics_ctx_lane_count(self._h))
 
     def stats(self):
         """felics_get_stats: batches redone (slot overflow, look-back fallback), slow-path / failed flags."""

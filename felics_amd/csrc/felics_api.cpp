@@ -65,9 +65,6 @@ struct Lane {
     uint32_t epoch = 0;               // sub-batches this lane has run: block tags are (epoch, slice)
     // the submission in flight on this lane (felics_submit_batch_device .. felics_wait_batch)
     bool pending = false;
-    bool tail_pending = false;        // queued on the shared stream: the front and the spine are queued, k + pack are not yet (run_lane)
-    bool m_two_pass = false;          // the context's pack / assign mode when this sub-batch's front was queued (its tail uses the same)
-    int m_assign = 0;
     bool finished = false;            // it took the synchronous path: results are in r_off / r_len / r_rc
     size_t p_n = 0;
     const void *p_pixels = nullptr;
@@ -89,37 +86,22 @@ struct Lane {
 
 struct felics_ctx {
     int device = -1;
-    // FELICS_SCHED=shared: queued submissions (felics_submit_batch_device) put all their GPU-filling kernels on ONE stream shared
-    // by the lanes, in an order the host chooses: front of batch i + 1 (histogram, offsets, scatter), then k + pack of batch i
-    // -- the tail of a batch is queued when the next batch is submitted (or when the batch is waited for).  Every one of these
-    // kernels is issue-bound, so two of them side by side only halve each other (the stages of a step sum to 2.6 ms of
-    // launches run alone and to 5.5 ms side by side); in this order each runs with the GPU to itself, only the spine of batch
-    // i + 1 underneath.  Built and measured in round 3: the kernels do run at their stand-alone speed, and the step is no
-    // shorter (see sched_shared) -- the default stays per-lane streams, everything side by side.
-    hipStream_t tstream = nullptr;
-    int defer_depth = 1;        // FELICS_DEFER
-    bool sched_shared = false;  // (measured round 3: 3.28-3.36 ms per step shared against 3.09-3.14 with per-lane streams: the spine of batch i + 1 -- its
-                                // helper waves sum every block of every chain -- takes a fifth of the issue slots from whatever runs beside it either way)
     int next_lane = 0;          // lane of the next felics_submit_batch_device
     int nlanes = DEFAULT_LANES; // lanes in use (FELICS_LANES)
     // Slices per sub-batch.  A blocking call has the GPU to itself: more slices let assign / pack follow the
     // spine closely.  With two submissions in flight the other batch keeps the GPU busy, and every slice costs
     // a launch and a hand-over per stage: few slices are faster there (measured: 12 -> 5.3, 6 -> 5.1, 3 -> 4.8 ms).
     int slices_blocking = 6;    // FELICS_SLICES
-    int slices_queued = 4;      // FELICS_SLICES_QUEUED
-    // Where the k of the events comes from (FELICS_ASSIGN):
-    //   gather (default): k_assign_serial replays every 64-event block once, one lane per block, and leaves k in chain
-    //                     order (k_sorted); the single-pass pack gathers it through the runs of its tile (k_pack_g)
-    //   inpack:           the single-pass pack computes k itself, in LDS, with wave-wide prefix sums (k_pack_k, round 2)
-    //   kernel:           k_assign scatters k to a byte per pixel in HBM (k_map), which the pack stages (round 1)
-    enum AssignMode { ASSIGN_GATHER = 0, ASSIGN_INPACK = 1, ASSIGN_KERNEL = 2 };
-    int assign_mode = ASSIGN_GATHER;
-    // k_pack_g takes its tiles from the workgroup index: the lanes share the tail stream, so one pack kernel has the look-back
-    // to itself.  A ticket counter (FELICS_TICKETS=1, and always with FELICS_OWN_TAILS) is one memory-side atomic per tile on one
-    // address -- 130 000 per step at the ~88 per microsecond one address sustains (MI355X_MICROARCH.md, dequeue): alone that
-    // is 1.5 ms per step (measured: the pack launches of a step 1.59 ms with the counter, 1.26 ms without).
+    int slices_queued = 4;      // (round 3 measured 2-4 lanes x 1-6 slices within 3 % of each other: profiles/r03/experiments.txt)
+    // k_pack_g takes its tiles from the workgroup index while the lanes share the tail stream: one pack kernel then has the
+    // look-back to itself.  With a tail stream per lane (FELICS_OWN_TAILS=1), and after a look-back has given up once, tiles are
+    // handed out by a ticket counter instead: a tile then only ever waits for tiles held by workgroups that are already running,
+    // whatever else shares the GPU.  The counter is one memory-side atomic per tile on one address -- 130 000 per step at the
+    // ~88 per microsecond one address sustains (MI355X_MICROARCH.md, dequeue) -- measured 1.59 against 1.26 ms of pack launches per step.
     bool pack_tickets = false;
-    bool two_pass = false;      // FELICS_TWO_PASS=1, or a look-back of the single-pass pack gave up once: lengths + pack kernels
+    bool two_pass = false;      // FELICS_TWO_PASS=1, or a look-back gave up with ticketed tiles as well: lengths + pack kernels
+    bool own_tails = false;     // FELICS_OWN_TAILS=1: a tail stream per lane (pack kernels of two submissions side by side, tiles by ticket)
+    bool serial = false;        // FELICS_SERIAL=1 (profiling tools: every kernel alone): all stages of a lane on one stream
     bool test_timeout = false;  // FELICS_TEST_TIMEOUT=1: every wait for the GPU reports a time-out (tests of the failed state)
     bool test_lookback = false; // FELICS_TEST_LOOKBACK_FAIL=1: pretend the first single-pass submission gave up (tests)
     bool poison = false;        // FELICS_POISON=1: overwrite the workspace before every sub-batch (tests)
@@ -190,7 +172,6 @@ int sync_lane(felics_ctx *ctx, Lane &l) {
     if (l.stream) HIP_TRY(ctx, hipStreamSynchronize(l.stream));
     if (l.kstream) HIP_TRY(ctx, hipStreamSynchronize(l.kstream));
     if (l.tail) HIP_TRY(ctx, hipStreamSynchronize(l.tail));
-    if (ctx->tstream) HIP_TRY(ctx, hipStreamSynchronize(ctx->tstream));
     return FELICS_OK;
 }
 
@@ -286,18 +267,19 @@ void header_bytes(uint8_t *o, uint32_t w, uint32_t h, int color, int depth) {
 //                  1 and 2 needs the size of the planes before them).
 // The stream sizes are copied to the lane's pinned buffer and `sized` is recorded behind them.
 // slot_stride == 0: no packing here (the caller places the streams exactly once it has the sizes).
-enum Phase { PH_ALL = 0, PH_FRONT = 1, PH_TAIL = 2 };  // run_lane: everything / up to the spine launches / k + pack + sizes
-
 template <typename T, typename ET>
-int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride, Phase phase, bool shared) {
+int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     const Geometry &g = l.g;
     const int ns = l.nslices;
     const size_t nsamples = (size_t)g.nplanes * g.npix;
     const size_t slots = (size_t)max_event_slots(g);
     int rc = 0;
-    if (phase != PH_TAIL) {
-    l.m_two_pass = ctx->two_pass;
-    l.m_assign = ctx->assign_mode;
+    // Fixed slots: code lengths, tile offsets and packing in one kernel per slice (k_pack_g; one such kernel at a time unless the
+    // tiles are handed out by ticket: the tiles of two of them waiting for each other's queued predecessors could hold all
+    // workgroup slots, so the lanes share the tail stream).  It puts planes 1, 2 of an RGB image into scratch slots of their
+    // own and moves them behind plane 0 at the end.  Otherwise (exact placement, FELICS_TWO_PASS, after a look-back gave up
+    // twice): k to a byte per pixel once every chain is replayed, then the lengths / bit scan / pack kernels over all tiles.
+    const bool fused = slot_stride != 0 && !ctx->two_pass;
     if ((rc = reserve(ctx, l.counts, (size_t)g.nplanes * g.sort_tiles * g.nctx * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.chain_len, (size_t)g.nplanes * g.nctx * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.chain_base, (size_t)g.nplanes * g.nctx * 4)) != 0) return rc;
@@ -305,12 +287,12 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride, Pha
     if ((rc = reserve(ctx, l.scalars, 64 + 4 * (SLICES + 2))) != 0) return rc;
     if ((rc = reserve(ctx, l.sorted_e, slots * sizeof(ET) + SORTED_PAD)) != 0) return rc;
     if ((rc = reserve(ctx, l.pix_of, slots * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, l.k_map, nsamples + STAGE_PAD)) != 0) return rc;
+    if (!fused && (rc = reserve(ctx, l.k_map, nsamples + STAGE_PAD)) != 0) return rc;
     if ((rc = reserve(ctx, l.k_sorted, slots + STAGE_PAD)) != 0) return rc;
     if ((rc = reserve(ctx, l.block_state, (size_t)max_event_blocks(g) * 32)) != 0) return rc;
     if ((rc = reserve(ctx, l.partial, (size_t)SLICES * g.nplanes * g.nctx * 8)) != 0) return rc;
     if ((rc = reserve_zeroed(ctx, l.block_tag, (size_t)max_event_blocks(g) * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, l.group_bits, (size_t)g.nplanes * g.pack_tiles * PACK_THREADS * 2)) != 0) return rc;
+    if (!fused && (rc = reserve(ctx, l.group_bits, (size_t)g.nplanes * g.pack_tiles * PACK_THREADS * 2)) != 0) return rc;
     if ((rc = reserve(ctx, l.tile_bits, (size_t)g.nplanes * g.pack_tiles * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.tile_bitoff, (size_t)g.nplanes * g.pack_tiles * 8)) != 0) return rc;
     if ((rc = reserve(ctx, l.plane_sums, (size_t)g.nplanes * 16)) != 0) return rc;  // carry[nplanes], base[nplanes]
@@ -326,11 +308,8 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride, Pha
         HIP_TRY(ctx, hipHostMalloc((void **)&l.h_sizes, hs * 8 + 64, hipHostMallocDefault));
         l.h_sizes_cap = hs;
     }
-
-    }
     hipStream_t s = l.stream, f = l.front, ks = l.kstream, tl = l.tail;
-    if (getenv("FELICS_SERIAL")) f = ks = tl = s;  // debugging aid: one stream, same order of launches
-    if (shared) f = ks = tl = ctx->tstream;        // (see felics_ctx::tstream)
+    if (ctx->serial) f = ks = tl = s;  // FELICS_SERIAL (profiling: every kernel alone): one stream, same order of launches
     const T *d_planes = (const T *)l.d_planes;
     auto *counts = (uint32_t *)l.counts.p;
     auto *chain_len = (uint32_t *)l.chain_len.p;
@@ -339,25 +318,12 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride, Pha
     auto *plane_carry = (uint64_t *)l.plane_sums.p;
     auto *plane_base = plane_carry + g.nplanes;
     // tags of other sub-batches never match this epoch (the lane's tags are cleared when the counter wraps)
-    if (phase != PH_TAIL) {
-        if (++l.epoch >= 0x03FFFFFFu) {
-            HIP_TRY(ctx, hipMemset(l.block_tag.p, 0, l.block_tag.cap));
-            l.epoch = 1;
-        }
-        if ((l.epoch & 0x3FFFFu) == 0) HIP_TRY(ctx, hipMemset(l.status.p, 0, l.status.cap));  // look-back tags: 18 epoch bits
+    if (++l.epoch >= 0x03FFFFFFu) {
+        HIP_TRY(ctx, hipMemset(l.block_tag.p, 0, l.block_tag.cap));
+        l.epoch = 1;
     }
+    if ((l.epoch & 0x3FFFFu) == 0) HIP_TRY(ctx, hipMemset(l.status.p, 0, l.status.cap));  // look-back tags: 18 epoch bits
     const uint32_t epoch = l.epoch;
-    // Fixed slots: code lengths, tile offsets and packing in one kernel per slice (one such kernel at a
-    // time: the tiles of two of them waiting for each other's queued predecessors could hold all workgroup
-    // slots, so the lanes share the tail stream).  It puts planes 1, 2 of an RGB image into scratch slots of
-    // their own and moves them behind plane 0 at the end.
-    const bool fused = slot_stride != 0 && !l.m_two_pass;
-    const bool ink = fused && l.m_assign == felics_ctx::ASSIGN_INPACK;  // k inside the pack kernel: the k stream has nothing to do
-    const bool gather = fused && l.m_assign == felics_ctx::ASSIGN_GATHER;  // k in chain order (k stream), gathered by the pack kernel
-    const bool rel = ink || gather;  // the pack kernel knows its tile: pix_of holds 16-bit offsets into the sort tile
-    // Two-pass kernels: gray frames pack slice by slice; RGB packs after the last slice (the offset of planes
-    // 1 and 2 in their stream needs the size of the planes before them).
-    const bool pack_by_slice = slot_stride != 0 && g.planes_per_image == 1;
     PackTarget target{d_out, slot_stride, nullptr, 0};
     if (fused && g.planes_per_image > 1) {
         target.plane_slot = ((uint64_t)g.npix + g.npix / 4 + 64 + 15) & ~15ull;
@@ -367,12 +333,8 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride, Pha
     uint32_t *d_error = (uint32_t *)l.scalars.p + 8;  // look-back watchdog of the single-pass pack
     uint32_t *d_tickets = (uint32_t *)l.scalars.p + 16;  // one per pack launch of this sub-batch: tiles are handed out in order
 
-    uint32_t bounds[SLICES + 1], pbounds[SLICES + 1];  // slice boundaries in sort tiles / pack tiles
-    for (int q = 0; q <= ns; q++) {
-        bounds[q] = (uint32_t)((uint64_t)g.sort_tiles * q / ns);
-        pbounds[q] = q == ns ? g.pack_tiles : std::min<uint32_t>(g.pack_tiles, bounds[q] * (SORT_TILE / PACK_TILE));
-    }
-    if (phase != PH_TAIL) {
+    uint32_t bounds[SLICES + 1];  // slice boundaries in sort tiles (= pack tiles)
+    for (int q = 0; q <= ns; q++) bounds[q] = (uint32_t)((uint64_t)g.sort_tiles * q / ns);
     // ---- front stream
     if (ctx->poison) {  // FELICS_POISON: every intermediate buffer starts as garbage, as on a fresh context
         DevBuf *bufs[] = {&l.counts, &l.chain_len, &l.chain_base, &l.sorted_e, &l.pix_of, &l.k_map, &l.k_sorted, &l.block_state,
@@ -387,14 +349,15 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride, Pha
     {
         StageTimer t(ctx, l, ST_OFFSETS, f);
         launch_offsets(f, counts, chain_len, chain_base, (uint32_t *)l.scalars.p, g);
-        launch_zero_padding<ET>(f, (ET *)l.sorted_e.p, rel ? nullptr : (uint32_t *)l.pix_of.p, chain_base, chain_len, g);
+        launch_zero_padding<ET>(f, (ET *)l.sorted_e.p, fused ? nullptr : (uint32_t *)l.pix_of.p, chain_base, chain_len, g);
         HIP_TRY(ctx, hipMemsetAsync(chain_prog, 0, (size_t)g.nplanes * g.nctx * 32, f));
         HIP_TRY(ctx, hipMemsetAsync(l.partial.p, 0, (size_t)ns * g.nplanes * g.nctx * 8, f));
     }
     for (int q = 0; q < ns; q++) {
         if (bounds[q + 1] != bounds[q]) {
             StageTimer t(ctx, l, ST_SCATTER, f, true);
-            launch_scatter<T, ET>(f, d_planes, counts, chain_base, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, rel, g,
+            // (the single-pass pack knows its tile: pix_of then holds 16-bit offsets into the sort tile)
+            launch_scatter<T, ET>(f, d_planes, counts, chain_base, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, fused, g,
                                   bounds[q], bounds[q + 1]);
         }
         HIP_TRY(ctx, hipEventRecord(l.slice_done[q], f));
@@ -410,92 +373,64 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride, Pha
         }
         HIP_TRY(ctx, hipEventRecord(l.spine_done[q], s));
     }
-    }
-    if (phase == PH_FRONT) {
-        HIP_TRY(ctx, hipGetLastError());
-        return FELICS_OK;
-    }
-    // ---- k stream: behind every spine launch, k of the events it published
-    for (int q = 0; q < ns && !ink; q++) {
+    // ---- k stream: behind every spine launch, k of the events it published, in chain order
+    for (int q = 0; q < ns; q++) {
         HIP_TRY(ctx, hipStreamWaitEvent(ks, l.spine_done[q], 0));
         if (bounds[q + 1] != bounds[q] || q + 1 == ns) {
             StageTimer t(ctx, l, ST_ASSIGN, ks, true);
-            if (gather)
-                launch_assign_serial<ET>(ks, (const ET *)l.sorted_e.p, (uint8_t *)l.k_sorted.p, (const uint32_t *)l.block_state.p,
-                                         (const uint32_t *)l.scalars.p, (const uint32_t *)l.block_tag.p,
-                                         (const uint32_t *)l.partial.p, epoch, (uint32_t)q + 1, g);
-            else
-                launch_assign<ET>(ks, (const ET *)l.sorted_e.p, (const uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
-                                  (const uint32_t *)l.block_state.p, (const uint32_t *)l.scalars.p,
-                                  (const uint32_t *)l.block_tag.p, (const uint32_t *)l.partial.p, epoch, (uint32_t)q + 1, g);
+            launch_assign_serial<ET>(ks, (const ET *)l.sorted_e.p, (uint8_t *)l.k_sorted.p, (const uint32_t *)l.block_state.p,
+                                     (const uint32_t *)l.scalars.p, (const uint32_t *)l.block_tag.p,
+                                     (const uint32_t *)l.partial.p, epoch, (uint32_t)q + 1, g);
         }
         HIP_TRY(ctx, hipEventRecord(l.assign_done[q], ks));
     }
-    // ---- tail stream: code lengths, bit offsets and (with fixed slots) the packed bits of each slice's tiles
+    // ---- tail stream
     HIP_TRY(ctx, hipMemsetAsync(plane_carry, 0, (size_t)g.nplanes * 16, tl));
     HIP_TRY(ctx, hipMemsetAsync(d_error, 0, 4, tl));
     HIP_TRY(ctx, hipMemsetAsync(d_tickets, 0, 4 * (SLICES + 2), tl));
-    for (int q = 0; q < ns; q++) {
-        const bool last = q + 1 == ns;
-        HIP_TRY(ctx, hipStreamWaitEvent(tl, ink ? l.spine_done[q] : l.assign_done[q], 0));
-        if (bounds[q + 1] == bounds[q] && !last) continue;
-        if (gather) {
+    if (fused) {
+        // behind every k launch: the packed bits of that slice's tiles
+        for (int q = 0; q < ns; q++) {
+            HIP_TRY(ctx, hipStreamWaitEvent(tl, l.assign_done[q], 0));
+            if (bounds[q + 1] == bounds[q]) continue;
             StageTimer t(ctx, l, ST_PACK, tl, true);
             launch_pack_g<T>(tl, d_planes, (const uint8_t *)l.k_sorted.p, (const uint32_t *)l.pix_of.p, counts, chain_base, chain_len,
                              (uint64_t *)l.status.p, (uint64_t *)l.tile_bitoff.p, (uint32_t *)l.tile_bits.p, plane_carry,
                              (uint32_t *)l.edge_first.p, (uint32_t *)l.edge_last.p, d_error, target, g, bounds[q], bounds[q + 1], epoch,
                              ctx->pack_tickets ? d_tickets + q : nullptr);
-        } else if (ink) {
-            {
-                StageTimer t(ctx, l, ST_PACK, tl, true);
-                launch_pack_k<T, ET>(tl, d_planes, (const ET *)l.sorted_e.p, (const uint32_t *)l.pix_of.p, (const uint32_t *)l.block_state.p,
-                                     counts, chain_base, chain_len, (uint64_t *)l.status.p, (uint64_t *)l.tile_bitoff.p,
-                                     (uint32_t *)l.tile_bits.p, plane_carry, (uint32_t *)l.edge_first.p, (uint32_t *)l.edge_last.p, d_error,
-                                     target, g, bounds[q], bounds[q + 1], epoch, d_tickets + q);
-            }
-        } else if (fused) {
-            {
-                StageTimer t(ctx, l, ST_PACK, tl, true);
-                launch_pack_fused<T>(tl, d_planes, (const uint8_t *)l.k_map.p, (uint64_t *)l.status.p,
-                                     (uint64_t *)l.tile_bitoff.p, (uint32_t *)l.tile_bits.p, plane_carry,
-                                     (uint32_t *)l.edge_first.p, (uint32_t *)l.edge_last.p, d_error, target, g, pbounds[q],
-                                     pbounds[q + 1], epoch, d_tickets + q);
-            }
         }
-        if (fused) {
-            if (last) {
-                StageTimer t(ctx, l, ST_ZERO, tl);
-                launch_finish_sizes(tl, plane_carry, plane_base, (uint64_t *)l.image_bytes.p, g);
-                launch_join_edges(tl, (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p,
-                                  (const uint32_t *)l.edge_first.p, (const uint32_t *)l.edge_last.p, target, g);
-                launch_concat_planes(tl, plane_base, plane_carry, target, g);
-            }
-            continue;
+        StageTimer t(ctx, l, ST_ZERO, tl);
+        launch_finish_sizes(tl, plane_carry, plane_base, (uint64_t *)l.image_bytes.p, g);
+        launch_join_edges(tl, (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p,
+                          (const uint32_t *)l.edge_first.p, (const uint32_t *)l.edge_last.p, target, g);
+        launch_concat_planes(tl, plane_base, plane_carry, target, g);
+    } else {
+        HIP_TRY(ctx, hipStreamWaitEvent(tl, l.assign_done[ns - 1], 0));
+        {
+            StageTimer t(ctx, l, ST_ASSIGN, tl, true);
+            launch_k_to_pixels(tl, (const uint8_t *)l.k_sorted.p, (const uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
+                               (const uint32_t *)l.scalars.p, g);
         }
         {
             StageTimer t(ctx, l, ST_LENGTHS, tl, true);
             launch_lengths<T>(tl, d_planes, (const uint8_t *)l.k_map.p, (uint16_t *)l.group_bits.p,
-                              (uint32_t *)l.tile_bits.p, g, pbounds[q], pbounds[q + 1]);
+                              (uint32_t *)l.tile_bits.p, g, 0, g.pack_tiles);
         }
         {
             StageTimer t(ctx, l, ST_BITSCAN, tl);
-            launch_bitscan_slice(tl, (const uint32_t *)l.tile_bits.p, (uint64_t *)l.tile_bitoff.p, plane_carry, g,
-                                 pbounds[q], pbounds[q + 1]);
-            if (last) launch_finish_sizes(tl, plane_carry, plane_base, (uint64_t *)l.image_bytes.p, g);
+            launch_bitscan_slice(tl, (const uint32_t *)l.tile_bits.p, (uint64_t *)l.tile_bitoff.p, plane_carry, g, 0, g.pack_tiles);
+            launch_finish_sizes(tl, plane_carry, plane_base, (uint64_t *)l.image_bytes.p, g);
         }
-        if (slot_stride != 0 && (pack_by_slice || last)) {
-            const uint32_t t0 = pack_by_slice ? pbounds[q] : 0, t1 = pbounds[q + 1];
+        if (slot_stride != 0) {
             {
                 StageTimer t(ctx, l, ST_ZERO, tl);
                 launch_zero_edges(tl, d_out, nullptr, slot_stride, (const uint64_t *)l.tile_bitoff.p,
-                                  (const uint32_t *)l.tile_bits.p, plane_base, g, t0, t1);
+                                  (const uint32_t *)l.tile_bits.p, plane_base, g, 0, g.pack_tiles);
             }
-            {
-                StageTimer t(ctx, l, ST_PACK, tl, true);
-                launch_pack<T>(tl, d_planes, (const uint8_t *)l.k_map.p, (const uint16_t *)l.group_bits.p,
-                               (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p, plane_base, nullptr,
-                               slot_stride, d_out, g, t0, t1);
-            }
+            StageTimer t(ctx, l, ST_PACK, tl, true);
+            launch_pack<T>(tl, d_planes, (const uint8_t *)l.k_map.p, (const uint16_t *)l.group_bits.p,
+                           (const uint64_t *)l.tile_bitoff.p, (const uint32_t *)l.tile_bits.p, plane_base, nullptr,
+                           slot_stride, d_out, g, 0, g.pack_tiles);
         }
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -656,10 +591,7 @@ size_t max_images_per_pass(uint64_t npix, uint32_t planes, int depth) {
 // Queues one sub-batch (cnt frames starting at frame `first` of d_pixels) on a lane: geometry, colour
 // transform, and everything run_lane / run_wide enqueue.  Returns without waiting.
 int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const void *d_pixels, uint32_t w, uint32_t h,
-                     int color, int depth, uint8_t *lane_out, uint64_t slot, int nslices, Phase phase = PH_ALL, bool shared = false) {
-    if (phase == PH_TAIL)  // the geometry is the lane's (launch_sub_batch ... PH_FRONT set it)
-        return l.g.planes_per_image == 3 ? run_lane<int16_t, uint16_t>(ctx, l, lane_out, slot, PH_TAIL, shared)
-                                         : run_lane<uint8_t, uint8_t>(ctx, l, lane_out, slot, PH_TAIL, shared);
+                     int color, int depth, uint8_t *lane_out, uint64_t slot, int nslices) {
     l.nslices = std::max(1, std::min(nslices, SLICES));
     ctx->stats.submissions++;
     const uint32_t planes = color == FELICS_COLOR_RGB ? 3 : 1;
@@ -683,10 +615,10 @@ int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const v
     const uint8_t *src = (const uint8_t *)d_pixels + first * frame_bytes;
     l.d_planes = src;
     if (ctx->profiling)  // on the stream the sub-batch's first kernel runs on
-        HIP_TRY(ctx, hipEventRecord(l.span_begin, wide || getenv("FELICS_SERIAL") ? l.stream : shared ? ctx->tstream : l.front));
+        HIP_TRY(ctx, hipEventRecord(l.span_begin, wide || ctx->serial ? l.stream : l.front));
     if (planes == 3) {
         if ((rc = reserve(ctx, l.planes, (size_t)g.nplanes * npix * (wide ? 4 : 2) + STAGE_PAD)) != 0) return rc;
-        hipStream_t fs = wide || getenv("FELICS_SERIAL") ? l.stream : shared ? ctx->tstream : l.front;
+        hipStream_t fs = wide || ctx->serial ? l.stream : l.front;
         StageTimer t(ctx, l, ST_PLANES, fs, true);
         if (wide)
             launch_rgb16_to_planes(fs, (const uint16_t *)src, (int32_t *)l.planes.p, g.npix, g.nimages);
@@ -695,7 +627,7 @@ int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const v
         l.d_planes = l.planes.p;
     }
     if (wide) return planes == 3 ? run_wide<int32_t>(ctx, l, lane_out, slot) : run_wide<uint16_t>(ctx, l, lane_out, slot);
-    return planes == 3 ? run_lane<int16_t, uint16_t>(ctx, l, lane_out, slot, phase, shared) : run_lane<uint8_t, uint8_t>(ctx, l, lane_out, slot, phase, shared);
+    return planes == 3 ? run_lane<int16_t, uint16_t>(ctx, l, lane_out, slot) : run_lane<uint8_t, uint8_t>(ctx, l, lane_out, slot);
 }
 
 // What the sizes that came back say about a sub-batch packed into fixed slots.
@@ -714,6 +646,24 @@ SlotOutcome read_sizes(felics_ctx *ctx, Lane &l, bool wide, uint64_t slot, uint6
         if (slot != 0 && l.h_sizes[i] > slot) o.overflow = true;
     }
     return o;
+}
+
+// A tile of the single-pass pack gave up waiting for the tiles before it.  With tiles taken from the workgroup index that can
+// be this context's own doing (a predecessor's workgroup not started yet: XCDs dispatch their shares of a grid independently
+// and the other lane's kernels share them), so the first remedy is the ticket counter -- same kernel, a tile then only waits
+// for workgroups that are running.  If a ticketed pack gives up as well, something else holds the GPU for a second at a time:
+// the context packs with the two-pass kernels from then on.
+void note_lookback_failure(felics_ctx *ctx) {
+    ctx->stats.lookback_fallbacks++;
+    if (!ctx->pack_tickets) {
+        ctx->pack_tickets = true;
+        ctx->stats.ticket_retries++;
+        ctx->err = "a tile gave up waiting for its predecessors: this context now hands its pack tiles out by ticket";
+    } else {
+        ctx->two_pass = true;
+        ctx->stats.two_pass = 1;
+        ctx->err = "a tile gave up waiting for its predecessors: this context now packs with the two-pass kernels (slower)";
+    }
 }
 
 // Encode `n` same-shape frames resident in device memory into d_out (device), on one lane, and wait.
@@ -775,7 +725,7 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
     }
     if (start_exact) slot = 0;
 
-    for (int attempt = 0; attempt < 3; attempt++) {
+    for (int attempt = 0; attempt < 4; attempt++) {  // (at most: tickets, two-pass, exact placement, and the run that succeeds)
         size_t done = 0;
         uint64_t out_base = 0;  // exact placement: where the next pass's streams start
         SlotOutcome outcome;
@@ -823,13 +773,8 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
             done = first;
         }
         if (outcome.lookback_failed) {
-            // A tile of the single-pass pack gave up waiting for the tiles before it (another context's
-            // kernels holding the GPU, most likely): this context packs in two passes from now on.
             if ((rc = sync_lane(ctx, l)) != 0) return rc;
-            ctx->stats.lookback_fallbacks++;
-            ctx->two_pass = true;
-            ctx->stats.two_pass = 1;
-            ctx->err = "a tile gave up waiting for its predecessors: this context now packs with the two-pass kernels (slower)";
+            note_lookback_failure(ctx);
             continue;
         }
         if (!outcome.overflow) break;
@@ -838,26 +783,6 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
     }
     collect_timing(ctx, l);
     if (used_out) *used_out = d_out;
-    return FELICS_OK;
-}
-
-// Queues deferred tails (k + pack + sizes) on the shared stream, oldest submission first.  The lanes are taken in turn, so
-// the oldest submission is on the lane the next submission will take (next_lane); `last` is the lane of the newest
-// submission whose tail is wanted: the one before the submission just queued (felics_submit_batch_device), or the one
-// being waited for (felics_wait_batch) -- a newer submission's tail stays deferred, behind the front of its successor.
-int flush_tails(felics_ctx *ctx, int first, int last) {
-    for (int li = first;; li = (li + 1) % ctx->nlanes) {
-        Lane &o = ctx->lanes[li];
-        if (o.tail_pending) {
-            o.tail_pending = false;
-            const int rc = launch_sub_batch(ctx, o, 0, o.p_n, o.p_pixels, o.p_w, o.p_h, o.p_color, o.p_depth, o.p_out, o.p_slot, 0, PH_TAIL, true);
-            if (rc) {
-                (void)sync_lane(ctx, o);
-                return rc;
-            }
-        }
-        if (li == last) break;
-    }
     return FELICS_OK;
 }
 
@@ -892,13 +817,10 @@ int felics_ctx_create(int device, felics_ctx **out) {
     ctx->poison = getenv("FELICS_POISON") != nullptr;
     ctx->two_pass = getenv("FELICS_TWO_PASS") != nullptr;
     ctx->test_lookback = getenv("FELICS_TEST_LOOKBACK_FAIL") != nullptr;
-    if (const char *e = getenv("FELICS_ASSIGN"))
-        ctx->assign_mode = strcmp(e, "kernel") == 0 ? felics_ctx::ASSIGN_KERNEL : strcmp(e, "inpack") == 0 ? felics_ctx::ASSIGN_INPACK : felics_ctx::ASSIGN_GATHER;
-    if (const char *e = getenv("FELICS_TICKETS")) ctx->pack_tickets = atoi(e) != 0;
-    if (getenv("FELICS_OWN_TAILS")) ctx->pack_tickets = true;
+    ctx->pack_tickets = ctx->own_tails = getenv("FELICS_OWN_TAILS") != nullptr;
+    ctx->serial = getenv("FELICS_SERIAL") != nullptr;
     ctx->test_timeout = getenv("FELICS_TEST_TIMEOUT") != nullptr;
     if (const char *e = getenv("FELICS_SLICES")) ctx->slices_blocking = std::max(1, std::min(atoi(e), SLICES));
-    if (const char *e = getenv("FELICS_SLICES_QUEUED")) ctx->slices_queued = std::max(1, std::min(atoi(e), SLICES));
     ctx->trace = getenv("FELICS_TRACE") != nullptr;
     if (const char *e = getenv("FELICS_TIMEOUT_S")) ctx->timeout_s = std::max(1, atoi(e));
     bool ok = hipSetDevice(device) == hipSuccess;
@@ -909,14 +831,6 @@ int felics_ctx_create(int device, felics_ctx **out) {
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);  // numerically: low >= high
     int prio_spine = prio_high, prio_front = prio_low, prio_tail = prio_high;
-    if (const char *e = getenv("FELICS_PRIO")) {
-        if (strcmp(e, "flat") == 0) prio_spine = prio_front = prio_tail = 0;
-        if (strcmp(e, "frontfirst") == 0) prio_spine = prio_front = prio_high, prio_tail = prio_low;
-        if (strcmp(e, "tailonly") == 0) prio_spine = prio_front = prio_low, prio_tail = prio_high;
-    }
-    if (const char *e = getenv("FELICS_SCHED")) ctx->sched_shared = strcmp(e, "shared") == 0;
-    if (const char *e = getenv("FELICS_DEFER")) ctx->defer_depth = std::max(1, atoi(e));
-    ok = ok && hipStreamCreateWithPriority(&ctx->tstream, hipStreamNonBlocking, prio_front) == hipSuccess;
     for (int li = 0; li < ctx->nlanes; li++) {
         Lane &l = ctx->lanes[li];
         ok = ok && hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio_spine) == hipSuccess;
@@ -925,7 +839,7 @@ int felics_ctx_create(int device, felics_ctx **out) {
         // One tail stream for all lanes: the pack kernels of two submissions run one after the other (measured faster:
         // 4.6 vs 4.8 ms per step).  FELICS_OWN_TAILS=1 gives every lane its own; that is safe since the pack kernels hand
         // out their tiles by ticket (FusedArgs::ticket), it just is not faster.
-        if (&l == &ctx->lanes[0] || getenv("FELICS_OWN_TAILS"))
+        if (&l == &ctx->lanes[0] || ctx->own_tails)
             ok = ok && hipStreamCreateWithPriority(&l.tail, hipStreamNonBlocking, prio_tail) == hipSuccess;
         else
             l.tail = ctx->lanes[0].tail;
@@ -963,7 +877,6 @@ void felics_ctx_destroy(felics_ctx *ctx) {
     }
     for (Lane &l : ctx->lanes)
         if (l.tail) (void)hipStreamSynchronize(l.tail);
-    if (ctx->tstream) (void)hipStreamSynchronize(ctx->tstream);
     for (Lane &l : ctx->lanes) {
         DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map, &l.k_sorted,
                           &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.plane_sums, &l.image_bytes, &l.image_off,
@@ -987,7 +900,6 @@ void felics_ctx_destroy(felics_ctx *ctx) {
         if (l.stream) (void)hipStreamDestroy(l.stream);
         if (l.tail && (&l == &ctx->lanes[0] || l.tail != ctx->lanes[0].tail)) (void)hipStreamDestroy(l.tail);
     }
-    if (ctx->tstream) (void)hipStreamDestroy(ctx->tstream);
     release(ctx->in);
     release(ctx->out);
     release(ctx->dec_meta);
@@ -1050,17 +962,10 @@ int felics_submit_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels, 
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         for (int i = 0; i < ST_COUNT; i++) l.ev_used[i] = 0;
         l.p_slot = slot;
-        const bool defer = ctx->sched_shared && depth != FELICS_DEPTH_16;  // (the 16-bit path runs on one stream of its own as a whole)
-        if ((rc = launch_sub_batch(ctx, l, 0, n, d_pixels, w, h, color, depth, l.p_out, slot, ctx->slices_queued, defer ? PH_FRONT : PH_ALL, defer)) != 0) {
+        if ((rc = launch_sub_batch(ctx, l, 0, n, d_pixels, w, h, color, depth, l.p_out, slot, ctx->slices_queued)) != 0) {
             (void)sync_lane(ctx, l);
             return rc;
         }
-        l.tail_pending = defer;
-        // behind this batch's front: the tails (k + pack) of the batches submitted `defer_depth` and more submissions ago (oldest
-        // first); depth 1: front of batch i + 1, tail of batch i; depth 2 (three lanes or more): front i + 2, tail i -- the spine
-        // of a batch then has two steps to finish before its tail is due
-        const int depth = std::max(1, std::min(ctx->defer_depth, ctx->nlanes - 1));
-        if (ctx->nlanes > depth && (rc = flush_tails(ctx, (L + 1) % ctx->nlanes, (L + ctx->nlanes - depth) % ctx->nlanes)) != 0) return rc;
     }
     l.pending = true;
     *ticket = L;
@@ -1074,9 +979,6 @@ int felics_wait_batch(felics_ctx *ctx, int ticket, uint64_t *offsets, uint64_t *
     Lane &l = ctx->lanes[ticket];
     if (!l.pending) return FELICS_E_INVALID_ARGUMENT;
     if (!l.finished) {
-        // this batch's tail, if no later submission has queued it yet (and any older one's: callers may wait out of order)
-        int frc = flush_tails(ctx, ctx->next_lane, ticket);
-        if (frc) return frc;
         // the lane stays marked busy until its kernels are known to have finished: after a timeout nothing may
         // reuse or free its workspace
         const int wrc = wait_event(ctx, l.sized, "stream sizes");
@@ -1099,10 +1001,7 @@ int felics_wait_batch(felics_ctx *ctx, int ticket, uint64_t *offsets, uint64_t *
     // the rare cases: pack again on this lane, synchronously (two-pass kernels / exact placement)
     if ((rc = sync_lane(ctx, l)) != 0) return rc;
     if (o.lookback_failed) {
-        ctx->stats.lookback_fallbacks++;
-        ctx->two_pass = true;
-        ctx->stats.two_pass = 1;
-        ctx->err = "a tile gave up waiting for its predecessors: this context now packs with the two-pass kernels (slower)";
+        note_lookback_failure(ctx);
     } else {
         ctx->stats.slot_overflows++;
     }
@@ -1199,13 +1098,22 @@ int felics_decompress_batch_device(felics_ctx *ctx, size_t n, const void *d_stre
     if (frame_bytes && !d_pixels) return fail_all(FELICS_E_INVALID_ARGUMENT);
     // a stream of this shape is never longer than this: a caller's length beyond it is not a stream (and not a size to allocate)
     const uint64_t max_len = felics_max_compressed_size(hdr.width, hdr.height, hdr.color_type, hdr.pixel_depth);
-    if (bps == 2 && decode16_lds_bytes(hdr.width) <= DECODE_LDS_LIMIT && !getenv("FELICS_DECODE16_HOST")) {
+    if (bps == 2 && decode16_lds_bytes(hdr.width) <= DECODE_LDS_LIMIT) {
         // 16-bit streams on the device: passes of at most DEC16_PASS streams (a stream's estimator table is 8.4 MB of HBM)
+        // (and of at most a quarter of the free HBM; an allocation that fails all the same halves the pass)
         constexpr size_t DEC16_PASS = 1024;
-        const size_t per = std::min(n, DEC16_PASS);
-        const size_t table_bytes = decode16_table_bytes((uint32_t)per);
-        if (table_bytes > ctx->dec_table.cap) ctx->dec_epoch = 0;  // a fresh (zeroed) buffer: epochs start over
-        if ((rc = reserve_zeroed(ctx, ctx->dec_table, table_bytes)) != 0) return fail_all(rc);
+        size_t per = std::min(n, DEC16_PASS);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && ctx->dec_table.cap < decode16_table_bytes((uint32_t)per))
+            per = std::max<size_t>(1, std::min(per, (free_b / 4 + ctx->dec_table.cap) / decode16_table_bytes(1)));
+        for (;;) {
+            const size_t table_bytes = decode16_table_bytes((uint32_t)per);
+            if (table_bytes > ctx->dec_table.cap) ctx->dec_epoch = 0;  // a fresh (zeroed) buffer: epochs start over
+            if ((rc = reserve_zeroed(ctx, ctx->dec_table, table_bytes)) == 0) break;
+            (void)hipGetLastError();
+            if (per == 1) return fail_all(rc);
+            per = (per + 1) / 2;
+        }
         if ((rc = reserve(ctx, ctx->dec_meta, per * 8 * 2 + per * 4)) != 0) return fail_all(rc);
         int32_t *d_planes32 = nullptr;
         if (planes == 3) {
@@ -1348,6 +1256,8 @@ int felics_get_stats(const felics_ctx *ctx, felics_stats *out) {
 int felics_stage_count(void) { return ST_COUNT; }
 
 int felics_lane_count(void) { return lanes_from_env(); }
+
+int felics_ctx_lane_count(const felics_ctx *ctx) { return ctx ? ctx->nlanes : FELICS_E_INVALID_ARGUMENT; }
 
 int felics_get_stage_launches(const felics_ctx *ctx, int *launches, int cap) {
     if (!ctx || !launches) return FELICS_E_INVALID_ARGUMENT;

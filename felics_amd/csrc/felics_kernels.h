@@ -19,7 +19,7 @@ constexpr uint32_t nctx_of() {
     return sizeof(T) == 1 ? 256u : 512u;  // T = sample type (u8 / i16) or event type (u8 / u16)
 }
 // pixels one wave partitions by context in the hist / scatter stages.  Equal to the pack tile: the pack stage
-// computes k for exactly its own tile's events (k_pack_k), one look-back per workgroup.
+// gathers k for exactly its own tile's events (k_pack_g), one look-back per workgroup.
 constexpr uint32_t SORT_TILE = 4096;
 // pack stage: 256 threads x 16 consecutive pixels
 constexpr uint32_t PACK_THREADS = 256;
@@ -79,8 +79,8 @@ void launch_offsets(hipStream_t s, uint32_t *counts, uint32_t *chain_len, uint32
 template <typename T, typename ET>
 void launch_scatter(hipStream_t s, const T *planes, const uint32_t *tile_off, const uint32_t *chain_base,
                     ET *sorted_e, uint32_t *pix_of, bool in_tile_offsets, const Geometry &g, uint32_t tile_begin, uint32_t tile_end);
-// pix_of holds, per event slot, where the event's pixel is: plane * npix + i as 32 bits (k_assign writes k by pixel), or
-// -- in_tile_offsets, for launch_pack_k, whose workgroups know their tile -- i - tile * SORT_TILE as 16 bits in the same
+// pix_of holds, per event slot, where the event's pixel is: plane * npix + i as 32 bits (launch_k_to_pixels writes k by pixel), or
+// -- in_tile_offsets, for launch_pack_g, whose workgroups know their tile -- i - tile * SORT_TILE as 16 bits in the same
 // buffer (launch_zero_padding then gets a null pix_of: the padding slots are never read).
 
 // Chains are padded to whole 64-event blocks: upper bounds of the slot / block counts of a pass.
@@ -109,12 +109,6 @@ template <typename ET>
 void launch_spine(hipStream_t s, const ET *sorted_e, uint32_t *block_state, const uint32_t *chain_base,
                   const uint32_t *chain_len, const uint32_t *tile_off, uint32_t t_end, uint32_t *chain_prog,
                   uint32_t *block_tag, uint32_t *partial, uint32_t epoch, uint32_t slice, const Geometry &g);
-
-// serves what the spine launch of `slice` published: the blocks it resolved and its partial blocks
-template <typename ET>
-void launch_assign(hipStream_t s, const ET *sorted_e, const uint32_t *pix_of, uint8_t *k_map,
-                   const uint32_t *block_state, const uint32_t *total_slots, const uint32_t *block_tag,
-                   const uint32_t *partial, uint32_t epoch, uint32_t slice, const Geometry &g);
 
 // lengths / bit scan / pack work on a range [t0, t1) of every plane's PACK tiles, so they can follow the
 // spine slice by slice.  tile_bitoff is relative to the plane; plane_base (zero for gray, set by
@@ -159,23 +153,9 @@ struct PackTarget {
     uint8_t *scratch;
     uint64_t plane_slot;
 };
-template <typename T>
-void launch_pack_fused(hipStream_t s, const T *planes, const uint8_t *k_map, uint64_t *status, uint64_t *tile_bitoff,
-                       uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last,
-                       uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t t0, uint32_t t1, uint32_t epoch,
-                       uint32_t *ticket /* one zeroed word per launch: tiles are handed out in order */);
-// The same pack with k computed inside it (k_pack_k): a workgroup takes one sort tile of [st0, st1) (= one pack tile),
-// runs the assign step on the 64-event blocks its events lie in (block states from the spine) and keeps k in LDS.
-// No k_map, no k_assign launch.
-template <typename T, typename ET>
-void launch_pack_k(hipStream_t s, const T *planes, const ET *sorted_e, const uint32_t *pix_of, const uint32_t *block_state,
-                   const uint32_t *tile_off, const uint32_t *chain_base, const uint32_t *chain_len, uint64_t *status,
-                   uint64_t *tile_bitoff, uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last,
-                   uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t st0, uint32_t st1, uint32_t epoch,
-                   uint32_t *ticket);
-// The same pack with k gathered from chain order (k_pack_g) and the kernel that puts it there (k_assign_serial: one lane
+// The single-pass pack with k gathered from chain order (k_pack_g) and the kernel that puts it there (k_assign_serial: one lane
 // replays one 64-event block, k_sorted[slot] = k of the event in that slot; launched per slice behind the spine like
-// launch_assign).  k_sorted needs max_event_slots() + STAGE_PAD bytes.
+// the spine).  k_sorted needs max_event_slots() + STAGE_PAD bytes.
 template <typename ET>
 void launch_assign_serial(hipStream_t s, const ET *sorted_e, uint8_t *k_sorted, const uint32_t *block_state,
                           const uint32_t *total_slots, const uint32_t *block_tag, const uint32_t *partial, uint32_t epoch,
@@ -185,6 +165,9 @@ void launch_pack_g(hipStream_t s, const T *planes, const uint8_t *k_sorted, cons
                    const uint32_t *chain_base, const uint32_t *chain_len, uint64_t *status, uint64_t *tile_bitoff,
                    uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last, uint32_t *error,
                    const PackTarget &to, const Geometry &g, uint32_t st0, uint32_t st1, uint32_t epoch, uint32_t *ticket);
+// two-pass pack: k from chain order (k_sorted) to a byte per pixel (k_map), all slots at once; pix_of = plane * npix + i
+void launch_k_to_pixels(hipStream_t s, const uint8_t *k_sorted, const uint32_t *pix_of, uint8_t *k_map, const uint32_t *total_slots,
+                         const Geometry &g);
 void launch_join_edges(hipStream_t s, const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint32_t *edge_first,
                        const uint32_t *edge_last, const PackTarget &to, const Geometry &g);
 void launch_concat_planes(hipStream_t s, const uint64_t *plane_base, const uint64_t *plane_carry, const PackTarget &to,

@@ -12,7 +12,7 @@
 //            (parameter_selection.rs:49-85): spine (sequential, per chain) + assign (parallel)
 //   pack     build the codes (rice_coding.rs:26-38, phase_in_coding.rs:59-84,
 //            compression.rs:29-45) and pack them MSB-first (bitstream-io BigEndian).
-//            Single pass (k_pack_fused: code lengths, tile offsets by decoupled look-back, packing),
+//            Single pass (k_pack_g: code lengths, tile offsets by decoupled look-back, packing),
 //            or two passes for exact placement / 16-bit samples / as a fallback:
 //   lengths    code length of every pixel -> bits per tile
 //   bitscan    exclusive scan of tile bits -> bit offset of every tile in its stream
@@ -284,7 +284,7 @@ __global__ void k_zero_padding(ET *__restrict__ sorted_e, uint32_t *__restrict__
 // scatter: stable partition of events by context.  One wave per tile walks its pixels in
 // raster order, 64 at a time; lanes that hold the same context rank themselves with a ballot.
 // sorted_e[slot] = value to Rice-code; pix_of[slot] = the pixel the event came from: plane*npix + i (32 bits) for
-// k_assign, or -- REL, what k_pack_k reads -- the pixel's offset in its sort tile (16 bits, the same buffer).
+// k_k_to_pixels (two-pass pack), or -- REL, what k_pack_g reads -- the pixel's offset in its sort tile (16 bits, the same buffer).
 // ------------------------------------------------------------------------------------------
 
 template <typename T, typename ET, bool REL>
@@ -621,17 +621,6 @@ __device__ __forceinline__ void spine_single(SpineSingleLDS<ET> &sh, const ET *_
 }
 
 
-template <typename ET>
-__global__ __launch_bounds__(64) void k_spine(const ET *__restrict__ sorted_e, uint32_t *__restrict__ block_state,
-                                              const uint32_t *__restrict__ chain_base,
-                                              const uint32_t *__restrict__ chain_len, uint32_t nchains,
-                                              const uint32_t *__restrict__ tile_off, uint32_t ntiles, uint32_t t_end,
-                                              uint32_t *__restrict__ chain_prog, uint32_t *__restrict__ block_tag,
-                                              uint2 *__restrict__ partial, uint32_t stamp) {
-    __shared__ SpineSingleLDS<ET> sh;
-    spine_single<ET>(sh, sorted_e, block_state, chain_base, chain_len, nchains, tile_off, ntiles, t_end, chain_prog, block_tag, partial, stamp);
-}
-
 // ------------------------------------------------------------------------------------------
 // k_spine2: the same walk with HELPER waves.  In k_spine the walker spends two thirds of a halving period building what
 // it needs to locate the halving: the block's per-event prefix sums (lengths, three packed DPP scans) and, once per batch,
@@ -877,166 +866,7 @@ __global__ __launch_bounds__(256) void k_spine2(const ET *__restrict__ sorted_e,
     }
 }
 
-// k of every event.  A block's record (k_spine) holds the estimator state at its first event; a wave
-// redoes the block's in-wave prefix sums and halvings and stores k at each event's pixel (k_map is in
-// raster order, one byte per sample; only event pixels are written).
-//
-// The kernel runs once per slice, right behind that slice's spine launch, and serves exactly what
-// that launch published: the blocks it resolved (block_tag == this epoch and slice) and, per chain, the
-// one block that has events in place but is not full yet (partial[chain] = {block, events}).  Later spine
-// launches may already be running: they tag other blocks and rewrite a partial block's record with the
-// same values, so nothing read here is in flux.  Waves scan 64 tags / 64 list entries at a time.
-constexpr uint32_t TAG_SLICE_BITS = 5;  // tag = epoch << 5 | slice
-
-// what a wave needs to serve one block: the block's record and, per lane, its event and its pixel
-struct BlockIn {
-    uint4 sa, sb;
-    uint32_t e, pix;
-};
-
-template <typename ET>
-__device__ __forceinline__ BlockIn load_block(const uint4 *__restrict__ st, const ET *__restrict__ sorted_e,
-                                              const uint32_t *__restrict__ pix_of, const uint32_t gb) {
-    BlockIn in;
-    in.sa = st[(uint64_t)gb * 2];
-    in.sb = st[(uint64_t)gb * 2 + 1];
-    in.e = (uint32_t)sorted_e[(uint64_t)gb * 64 + lane_id()];
-    in.pix = pix_of[(uint64_t)gb * 64 + lane_id()];
-    return in;
-}
-
-__device__ __forceinline__ void assign_block(const BlockIn &in, const uint32_t valid, uint8_t *__restrict__ k_map) {
-    const uint32_t lane = lane_id();
-    uint32_t S0 = in.sa.x, S1 = in.sa.y, S2 = in.sa.z, S3 = in.sa.w, S4 = in.sb.x, S5 = in.sb.y;
-    uint32_t l01, l23, l45;
-    packed_lengths(in.e, l01, l23, l45);
-    const uint32_t p01 = wave_incl_scan(l01), p23 = wave_incl_scan(l23), p45 = wave_incl_scan(l45);
-    const uint32_t P0 = p01 & 0xFFFFu, P1 = p01 >> 16, P2 = p23 & 0xFFFFu, P3 = p23 >> 16;
-    const uint32_t P4 = p45 & 0xFFFFu, P5 = p45 >> 16;
-    const uint32_t l0 = l01 & 0xFFFFu, l1 = l01 >> 16, l2 = l23 & 0xFFFFu, l3 = l23 >> 16, l4 = l45 & 0xFFFFu,
-                   l5 = l45 >> 16;
-    uint32_t kk = 0, lo = 0;
-    while (true) {
-        const uint32_t T0 = S0 + P0, T1 = S1 + P1, T2 = S2 + P2, T3 = S3 + P3, T4 = S4 + P4, T5 = S5 + P5;
-        const uint32_t mn = min(min(min(T0, T1), min(T2, T3)), min(T4, T5));
-        // state BEFORE this lane's event -> its k (get_k precedes update, compression.rs:127,139)
-        const uint32_t X0 = T0 - l0, X1 = T1 - l1, X2 = T2 - l2, X3 = T3 - l3, X4 = T4 - l4, X5 = T5 - l5;
-        const uint32_t key = min(min(min((X0 << 3) | 7u, (X1 << 3) | 6u), min((X2 << 3) | 5u, (X3 << 3) | 4u)),
-                                 min((X4 << 3) | 3u, (X5 << 3) | 2u));
-        const uint32_t cand = 7u - (key & 7u);
-        const uint64_t hm = __ballot(lane >= lo && mn > 1024u);
-        if (hm == 0) {
-            if (lane >= lo) kk = cand;
-            break;
-        }
-        const uint32_t f = (uint32_t)__ffsll((long long)hm) - 1u;
-        if (lane >= lo && lane <= f) kk = cand;
-        const uint32_t f0 = readlane(P0, f), f1 = readlane(P1, f), f2 = readlane(P2, f);
-        const uint32_t f3 = readlane(P3, f), f4 = readlane(P4, f), f5 = readlane(P5, f);
-        S0 = ((S0 + f0) >> 1) - f0; S1 = ((S1 + f1) >> 1) - f1; S2 = ((S2 + f2) >> 1) - f2;
-        S3 = ((S3 + f3) >> 1) - f3; S4 = ((S4 + f4) >> 1) - f4; S5 = ((S5 + f5) >> 1) - f5;
-        lo = f + 1;
-        if (lo >= 64) break;
-    }
-    // lanes past the block's events in place hold no event yet; padding slots belong to no pixel
-    if (lane < valid && in.pix != 0xFFFFFFFFu) k_map[in.pix] = (uint8_t)kk;
-}
-
-// The same for the pack stage's own use (k_pack_k): k goes to an LDS array indexed by the pixel's offset in the tile, only for
-// the lanes whose events belong to the caller's tile (`mine`); lanes at or behind `nlive` hold no event yet.
-// The block's start state arrives as one register (lane l holds S[l & 7], as the spine stored it), so that a ring of
-// prefetched blocks costs three registers per entry; it lives in scalar registers from here on.
-__device__ __forceinline__ void assign_block_lds(const uint32_t e, const uint32_t pix, const uint32_t st, const bool mine,
-                                                 const uint32_t nlive, uint8_t *kq) {
-    const uint32_t lane = lane_id();
-    uint32_t S0 = readlane(st, 0), S1 = readlane(st, 1), S2 = readlane(st, 2), S3 = readlane(st, 3), S4 = readlane(st, 4),
-             S5 = readlane(st, 5);
-    uint32_t l01, l23, l45;
-    packed_lengths(e, l01, l23, l45);
-    const uint32_t p01 = wave_incl_scan(l01), p23 = wave_incl_scan(l23), p45 = wave_incl_scan(l45);
-    const uint32_t P0 = p01 & 0xFFFFu, P1 = p01 >> 16, P2 = p23 & 0xFFFFu, P3 = p23 >> 16;
-    const uint32_t P4 = p45 & 0xFFFFu, P5 = p45 >> 16;
-    const uint32_t l0 = l01 & 0xFFFFu, l1 = l01 >> 16, l2 = l23 & 0xFFFFu, l3 = l23 >> 16, l4 = l45 & 0xFFFFu,
-                   l5 = l45 >> 16;
-    uint32_t kk = 0, lo = 0;
-    while (true) {
-        const uint32_t T0 = S0 + P0, T1 = S1 + P1, T2 = S2 + P2, T3 = S3 + P3, T4 = S4 + P4, T5 = S5 + P5;
-        const uint32_t mn = min(min(min(T0, T1), min(T2, T3)), min(T4, T5));
-        // state BEFORE this lane's event -> its k (get_k precedes update, compression.rs:127,139)
-        const uint32_t X0 = T0 - l0, X1 = T1 - l1, X2 = T2 - l2, X3 = T3 - l3, X4 = T4 - l4, X5 = T5 - l5;
-        const uint32_t key = min(min(min((X0 << 3) | 7u, (X1 << 3) | 6u), min((X2 << 3) | 5u, (X3 << 3) | 4u)),
-                                 min((X4 << 3) | 3u, (X5 << 3) | 2u));
-        const uint32_t cand = 7u - (key & 7u);
-        const uint64_t hm = __ballot(lane >= lo && lane < nlive && mn > 1024u);
-        if (hm == 0) {
-            if (lane >= lo) kk = cand;
-            break;
-        }
-        const uint32_t f = (uint32_t)__ffsll((long long)hm) - 1u;
-        if (lane >= lo && lane <= f) kk = cand;
-        const uint32_t f0 = readlane(P0, f), f1 = readlane(P1, f), f2 = readlane(P2, f);
-        const uint32_t f3 = readlane(P3, f), f4 = readlane(P4, f), f5 = readlane(P5, f);
-        S0 = ((S0 + f0) >> 1) - f0; S1 = ((S1 + f1) >> 1) - f1; S2 = ((S2 + f2) >> 1) - f2;
-        S3 = ((S3 + f3) >> 1) - f3; S4 = ((S4 + f4) >> 1) - f4; S5 = ((S5 + f5) >> 1) - f5;
-        lo = f + 1;
-        if (lo >= nlive) break;
-    }
-    if (mine) kq[pix] = (uint8_t)kk;
-}
-
-// Tags are dealt to the waves one by one (tag g belongs to wave g % nwaves): the blocks a spine launch
-// resolved are long runs of consecutive blocks of the long chains, and this way a run is shared by as
-// many waves as it has blocks.  While a block is computed the next block's loads are already in flight.
-template <typename ET>
-__global__ __launch_bounds__(256) void k_assign(const ET *__restrict__ sorted_e, const uint32_t *__restrict__ block_state,
-                                                const uint32_t *__restrict__ pix_of, uint8_t *__restrict__ k_map,
-                                                const uint32_t *__restrict__ total_slots,
-                                                const uint32_t *__restrict__ block_tag,
-                                                const uint2 *__restrict__ partial, uint32_t nchains, uint32_t stamp) {
-    const uint32_t lane = lane_id();
-    const uint32_t nblocks = *total_slots >> 6;
-    const uint32_t nwaves = gridDim.x * 4;
-    // (wave-uniform, and said so: block indices, the blocks' records and the six counters then live in scalar
-    // registers and the halvings are scalar arithmetic)
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    const uint4 *st = reinterpret_cast<const uint4 *>(block_state);
-    // blocks resolved by this slice's spine launch
-    for (uint32_t g0 = wave; g0 < nblocks; g0 += nwaves * 64) {
-        const uint64_t mine = (uint64_t)g0 + (uint64_t)lane * nwaves;
-        uint64_t todo = __ballot(mine < nblocks && block_tag[mine] == stamp);
-        if (todo == 0) continue;
-        uint32_t gb = g0 + ((uint32_t)__ffsll((long long)todo) - 1u) * nwaves;
-        todo &= todo - 1;
-        BlockIn cur = load_block<ET>(st, sorted_e, pix_of, gb);
-        while (true) {
-            const bool more = todo != 0;
-            BlockIn nxt = cur;
-            if (more) {
-                gb = g0 + ((uint32_t)__ffsll((long long)todo) - 1u) * nwaves;
-                todo &= todo - 1;
-                nxt = load_block<ET>(st, sorted_e, pix_of, gb);
-            }
-            assign_block(cur, 64u, k_map);
-            if (!more) break;
-            cur = nxt;
-        }
-    }
-    // per chain: the block with events in place that is not full yet (entries dealt like the tags: the
-    // chains that have one are neighbours in the list)
-    for (uint32_t c0 = wave; c0 < nchains; c0 += nwaves * 64) {
-        const uint64_t mine = (uint64_t)c0 + (uint64_t)lane * nwaves;
-        uint2 entry = make_uint2(0u, 0u);
-        if (mine < nchains) entry = partial[mine];
-        uint64_t todo = __ballot(entry.y != 0);
-        while (todo) {
-            const uint32_t b = (uint32_t)__ffsll((long long)todo) - 1u;
-            todo &= todo - 1;
-            const uint32_t gb = readlane(entry.x, b), valid = readlane(entry.y, b);
-            const BlockIn in = load_block<ET>(st, sorted_e, pix_of, gb);
-            assign_block(in, valid, k_map);
-        }
-    }
-}
+constexpr uint32_t TAG_SLICE_BITS = 5;  // a block's tag = epoch << 5 | slice of the spine launch that resolved it
 
 // ------------------------------------------------------------------------------------------
 // k of every event, in CHAIN order (k_assign_serial): one LANE per 64-event block.
@@ -1045,7 +875,7 @@ __global__ __launch_bounds__(256) void k_assign(const ET *__restrict__ sorted_e,
 // (parameter_selection.rs:49-85): k = argmin of the six counters, ties to the largest k (`<=` at :79), taken BEFORE the
 // update (compression.rs:127,139); update; halve when the minimum exceeds 1024.  No cross-lane operation: 64 lanes = 64
 // independent blocks, ~30 instructions per event instead of the ~290 lane-instructions per event of the wave-wide
-// prefix-sum form (assign_block), and every block is computed exactly once.  k leaves as one byte per event slot,
+// prefix-sum form of rounds 1-2, and every block is computed exactly once.  k leaves as one byte per event slot,
 // 64 consecutive bytes per lane (k_sorted[slot]): the pack stage gathers it through the runs of its tile
 // (k_pack_g), so nothing is scattered to pixel order in HBM.
 //
@@ -1157,6 +987,18 @@ __global__ __launch_bounds__(256) void k_assign_serial(const ET *__restrict__ so
             for (uint32_t b = 0; b < 4; b++) kk |= est.step((uint32_t)src[i + b]) << (8u * b);
             dst[i >> 2] = kk ^ 0x07070707u;
         }
+    }
+}
+
+// Two-pass pack only (exact placement after a slot overflow, FELICS_TWO_PASS, or after a look-back gave up): k from chain
+// order to a byte per pixel, k_map[pix_of[slot]] = k_sorted[slot], once every chain has been replayed.  pix_of holds
+// plane * npix + i here (k_scatter<.., false>), 0xFFFFFFFF in the padding slots of a chain's last block.
+__global__ __launch_bounds__(256) void k_k_to_pixels(const uint8_t *__restrict__ k_sorted, const uint32_t *__restrict__ pix_of,
+                                                     uint8_t *__restrict__ k_map, const uint32_t *__restrict__ total_slots) {
+    const uint32_t n = *total_slots;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t pix = pix_of[i];
+        if (pix != 0xFFFFFFFFu) k_map[pix] = k_sorted[i];
     }
 }
 
@@ -1649,7 +1491,7 @@ struct LocalBits {
     }
 };
 
-// The single-pass pack of ONE tile by a workgroup (the body of k_pack_fused and of k_pack_k): see the comment above.
+// The single-pass pack of ONE tile by a workgroup (the body of k_pack_g): see the comment above.
 // kq = the tile's k bytes in LDS; they are staged from k_map unless k_map is null (the caller has put them there).
 struct FusedArgs {
     uint64_t *status;
@@ -2038,156 +1880,6 @@ extern "C" __attribute__((visibility("default"))) int felics_debug_pack_stamps(u
 }
 #endif
 
-// (u8 planes: k_pack_k runs seven waves per SIMD -- 72 VGPRs, 22.6 KB of LDS per workgroup: private bit buffers of six words
-// and a window of 8 bits per pixel are what makes seven fit, 4.15 -> 3.99 ms per step; i16 planes: five, 30.8 KB)
-template <typename T>
-__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 4))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_fused(const T *__restrict__ planes, const uint8_t *__restrict__ k_map,
-                                                             FusedArgs fa, uint32_t tile_begin) {
-    __shared__ TileLDS<T> tl;
-    __shared__ FusedLDS fl;
-    uint32_t x, plane;
-    take_ticket(fa, fl, x, plane);
-    pack_tile_fused<T>(tl, tl.kq, fl, planes, k_map, fa, tile_begin + x, plane,
-                       group_geometry<T>(planes + (uint64_t)plane * fa.npix, tile_begin + x, fa.W, fa.npix));
-}
-
-// ------------------------------------------------------------------------------------------
-// pack with k computed in place (k_pack_k): a workgroup takes one tile (sort tile = pack tile).  Every context's
-// events of a sort tile are one run of slots in the context's chain (tile_off[t][c] .. tile_off[t + 1][c]); the
-// workgroup runs assign_block on exactly the 64-event blocks that overlap those runs (the blocks' start states
-// come from the spine) and keeps k in an LDS array indexed by pixel, then packs the tile.  There is no k per
-// pixel in HBM, and no pass that scatters one byte per event across it.
-// ------------------------------------------------------------------------------------------
-
-struct KSources {
-    const void *sorted_e;
-    const uint16_t *pix_of;  // offset of the event's pixel in its sort tile
-    const uint32_t *block_state, *tile_off, *chain_base, *chain_len;
-    uint32_t sort_ntiles;
-};
-
-template <typename T, typename ET>
-__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 5))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_k(const T *__restrict__ planes, KSources ks, FusedArgs fa,
-                                                                                               uint32_t sort_tile_begin, uint32_t pack_tile_end) {
-    __shared__ TileLDS<T> tl;
-    __shared__ FusedLDS fl;
-    static_assert(SORT_TILE == PACK_TILE, "one workgroup = one sort tile = one pack tile (one look-back per workgroup)");
-    uint8_t *kq2 = tl.kq;
-    uint32_t x, plane;
-#ifdef FELICS_PACK_STAMPS
-    if (threadIdx.x == 0) {
-        fl.t_last = __builtin_amdgcn_s_memtime();
-    }
-#endif
-    take_ticket(fa, fl, x, plane);
-    PSTAMP(0);
-    const uint32_t st = sort_tile_begin + x;
-    const uint32_t lane = lane_id();
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    constexpr uint32_t NWV = PACK_THREADS / 64;
-    // ---- k of this sort tile's events.  The 64-event blocks that overlap the tile's runs are listed in LDS first
-    // (thread t lists the blocks of context t -- and t + 256 for Y/Co/Cg planes; the list lives in the bit window and the private bit
-    // buffers, which the pack stage only uses afterwards) and then dealt to the waves one by one: a synthetic or
-    // smooth frame has ten contexts that matter, so dealing whole contexts leaves one wave with a third more blocks
-    // than the average.  (Listing the runs instead and letting every wave walk that list with scalar code was measured:
-    // what the listing saves, the walk costs.)
-    {
-        constexpr uint32_t NC = nctx_of<T>();
-        const uint32_t *off0 = ks.tile_off + ((uint64_t)plane * ks.sort_ntiles + st) * NC;
-        const bool last_tile = st + 1 == ks.sort_ntiles;
-        const uint32_t *off1 = last_tile ? ks.chain_len + (uint64_t)plane * NC : off0 + NC;
-        const uint32_t *cb = ks.chain_base + (uint64_t)plane * NC;
-        const ET *sorted_e = reinterpret_cast<const ET *>(ks.sorted_e);
-        constexpr uint32_t CPT = NC / PACK_THREADS;  // contexts per thread
-        static_assert(NC == CPT * PACK_THREADS, "thread t lists contexts t, t + PACK_THREADS, ...");
-        constexpr uint32_t MAX_ITEMS = SORT_TILE / 64 + 2 * NC;  // a run of L events touches at most L / 64 + 2 blocks
-        static_assert(2 * MAX_ITEMS <= FUSED_WIN_WORDS + LOCAL_WORDS * PACK_THREADS && offsetof(FusedLDS, win) == offsetof(FusedLDS, lbuf) + sizeof(fl.lbuf),
-                      "the block list borrows lbuf + win");
-        uint2 *items = reinterpret_cast<uint2 *>(fl.lbuf);  // {block, first lane of the run | lanes with an event in place << 8}
-        uint32_t ra[CPT], rb[CPT], rbase[CPT];
-#pragma unroll
-        for (uint32_t h = 0; h < CPT; h++) {
-            const uint32_t c = threadIdx.x + h * PACK_THREADS;
-            ra[h] = off0[c];
-            rb[h] = off1[c];
-            rbase[h] = cb[c];
-        }
-        // the tile's pixels come in on the same round trip as the run table (the pack stage reads them from LDS)
-        stage_pixels(tl, planes + (uint64_t)plane * fa.npix, st * PACK_TILE, fa.W, fa.npix);
-        uint32_t sa[CPT], sb[CPT], nb[CPT];
-        uint32_t mine_n = 0;
-#pragma unroll
-        for (uint32_t h = 0; h < CPT; h++) {
-            const uint32_t a = ra[h], b = rb[h], base = rbase[h];
-            sa[h] = a + base;
-            sb[h] = b + base;  // slots [sa, sb)
-            nb[h] = b > a ? ((sb[h] - 1) >> 6) - (sa[h] >> 6) + 1 : 0u;
-            mine_n += nb[h];
-        }
-        PSTAMP(9);
-        const uint32_t incl = wave_incl_scan(mine_n);
-        if (lane == 63) fl.wsum[wave] = incl;
-        __syncthreads();
-        PSTAMP(10);
-        uint32_t at = incl - mine_n, nitems = 0;
-        for (uint32_t w = 0; w < NWV; w++) {
-            if (w < wave) at += fl.wsum[w];
-            nitems += fl.wsum[w];
-        }
-#pragma unroll
-        for (uint32_t h = 0; h < CPT; h++) {
-            for (uint32_t j = 0; j < nb[h]; j++) {
-                const uint32_t gb = (sa[h] >> 6) + j;
-                const uint32_t lo = sa[h] > gb * 64u ? sa[h] - gb * 64u : 0u, hi = min(64u, sb[h] - gb * 64u);
-                items[at++] = make_uint2(gb, lo | (hi << 8));
-            }
-        }
-        __syncthreads();
-        PSTAMP(1);
-        nitems = (uint32_t)__builtin_amdgcn_readfirstlane((int)nitems);
-        // A wave's blocks go through a ring of AHEAD prefetched entries (event, pixel and start state: three registers
-        // each): with one block in flight per wave the stage was one memory round trip per block, ~19 in a row per tile.
-        // Every refill is issued whether or not the entry is used (the index is clamped), so the number of loads in
-        // flight is the same on every path.
-        constexpr uint32_t AHEAD = 6;
-        uint32_t re[AHEAD], rp[AHEAD], rs[AHEAD], rr[AHEAD];
-        const uint32_t *stw = ks.block_state;
-        auto fetch = [&](uint32_t &e, uint32_t &px, uint32_t &sv, uint32_t &rng, uint32_t idx) {
-            const uint2 it = items[min(idx, nitems - 1u)];
-            rng = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.y);
-            const uint32_t gb = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.x);
-            e = (uint32_t)sorted_e[(uint64_t)gb * 64 + lane];
-            px = (uint32_t)ks.pix_of[(uint64_t)gb * 64 + lane];
-            sv = stw[(uint64_t)gb * 8 + (lane & 7u)];
-        };
-        if (nitems != 0) {
-#pragma unroll
-            for (uint32_t d = 0; d < AHEAD; d++) {
-                fetch(re[d], rp[d], rs[d], rr[d], wave + d * NWV);
-                __builtin_amdgcn_sched_barrier(0);  // (entry 0 first: the loop consumes the entries in this order)
-            }
-            for (uint32_t i = wave; i < nitems; i += NWV * AHEAD) {
-#pragma unroll
-                for (uint32_t d = 0; d < AHEAD; d++) {
-                    const uint32_t idx = i + d * NWV;
-                    uint32_t e = re[d];
-                    const uint32_t px = rp[d], sv = rs[d], rng = rr[d];
-                    fetch(re[d], rp[d], rs[d], rr[d], idx + NWV * AHEAD);
-                    if (idx < nitems) {
-                        const uint32_t lo = rng & 0xFFu, hi = rng >> 8;
-                        if (lane >= hi) e = 0;  // not scattered yet (a later tile's events): whatever lies there is not an event
-                        assign_block_lds(e, px, sv, lane >= lo && lane < hi, hi, kq2);
-                    }
-                }
-            }
-        }
-    }
-    PSTAMP(2);
-    __syncthreads();
-    PSTAMP(3);
-    if (st < pack_tile_end) pack_tile_fused<T>(tl, kq2, fl, planes, nullptr, fa, st, plane, group_geometry<T>(planes + (uint64_t)plane * fa.npix, st, fa.W, fa.npix));
-}
-
 // ------------------------------------------------------------------------------------------
 // pack with k gathered from chain order (k_pack_g): a workgroup takes one tile (sort tile = pack tile).  k of every event
 // lies in k_sorted[slot] (k_assign_serial); the events of a sort tile in one context are one run of slots of that context's
@@ -2438,20 +2130,10 @@ void launch_spine(hipStream_t s, const ET *sorted_e, uint32_t *block_state, cons
                   const uint32_t *chain_len, const uint32_t *tile_off, uint32_t t_end, uint32_t *chain_prog,
                   uint32_t *block_tag, uint32_t *partial, uint32_t epoch, uint32_t slice, const Geometry &g) {
     const uint32_t nchains = g.nplanes * g.nctx;
-    static const bool helpers = [] {
-        const char *e = getenv("FELICS_SPINE");
-        return !(e && strcmp(e, "single") == 0);
-    }();  // FELICS_SPINE=single: the one-wave walk for every chain (k_spine)
-    if (helpers)
-        FELICS_LAUNCH((k_spine2<ET>), dim3(nchains), dim3(256), s, sorted_e, block_state, chain_base, chain_len,
-                           nchains, tile_off, g.sort_tiles, t_end, chain_prog, block_tag,
-                           reinterpret_cast<uint2 *>(partial) + (uint64_t)(slice - 1) * nchains,
-                           (epoch << TAG_SLICE_BITS) | slice);
-    else
-        FELICS_LAUNCH((k_spine<ET>), dim3(nchains), dim3(64), s, sorted_e, block_state, chain_base, chain_len,
-                           nchains, tile_off, g.sort_tiles, t_end, chain_prog, block_tag,
-                           reinterpret_cast<uint2 *>(partial) + (uint64_t)(slice - 1) * nchains,
-                           (epoch << TAG_SLICE_BITS) | slice);
+    FELICS_LAUNCH((k_spine2<ET>), dim3(nchains), dim3(256), s, sorted_e, block_state, chain_base, chain_len,
+                       nchains, tile_off, g.sort_tiles, t_end, chain_prog, block_tag,
+                       reinterpret_cast<uint2 *>(partial) + (uint64_t)(slice - 1) * nchains,
+                       (epoch << TAG_SLICE_BITS) | slice);
 }
 template void launch_spine<uint8_t>(hipStream_t, const uint8_t *, uint32_t *, const uint32_t *, const uint32_t *,
                                     const uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t,
@@ -2459,25 +2141,6 @@ template void launch_spine<uint8_t>(hipStream_t, const uint8_t *, uint32_t *, co
 template void launch_spine<uint16_t>(hipStream_t, const uint16_t *, uint32_t *, const uint32_t *, const uint32_t *,
                                      const uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t,
                                      const Geometry &);
-
-template <typename ET>
-void launch_assign(hipStream_t s, const ET *sorted_e, const uint32_t *pix_of, uint8_t *k_map,
-                   const uint32_t *block_state, const uint32_t *total_slots, const uint32_t *block_tag,
-                   const uint32_t *partial, uint32_t epoch, uint32_t slice, const Geometry &g) {
-    // persistent: 8 workgroups of 4 waves per CU walk all tags (fewer if there cannot be that many blocks)
-    const uint32_t nchains = g.nplanes * g.nctx;
-    const uint32_t max_blocks = max_event_blocks(g);
-    const uint32_t wgs = std::min<uint32_t>(cdiv(max_blocks, 4 * 64), 256u * 8u);
-    FELICS_LAUNCH((k_assign<ET>), dim3(wgs), dim3(256), s, sorted_e, block_state, pix_of, k_map, total_slots,
-                       block_tag, reinterpret_cast<const uint2 *>(partial) + (uint64_t)(slice - 1) * nchains, nchains,
-                       (epoch << TAG_SLICE_BITS) | slice);
-}
-template void launch_assign<uint8_t>(hipStream_t, const uint8_t *, const uint32_t *, uint8_t *, const uint32_t *,
-                                     const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, uint32_t,
-                                     const Geometry &);
-template void launch_assign<uint16_t>(hipStream_t, const uint16_t *, const uint32_t *, uint8_t *, const uint32_t *,
-                                      const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, uint32_t,
-                                      const Geometry &);
 
 template <typename T>
 void launch_lengths(hipStream_t s, const T *planes, const uint8_t *k_map, group_bits_t<T> *group_bits,
@@ -2549,46 +2212,6 @@ template void launch_pack<int32_t>(hipStream_t, const int32_t *, const uint8_t *
                                    const uint32_t *, const uint64_t *, const uint64_t *, uint64_t, uint8_t *,
                                    const Geometry &, uint32_t, uint32_t);
 
-template <typename T>
-void launch_pack_fused(hipStream_t s, const T *planes, const uint8_t *k_map, uint64_t *status, uint64_t *tile_bitoff,
-                       uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last,
-                       uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t t0, uint32_t t1, uint32_t epoch,
-                       uint32_t *ticket) {
-    if (t1 <= t0) return;
-    const FusedArgs fa{status, tile_bitoff, tile_bits, plane_carry, edge_first, edge_last, error,
-                       PlaneOut{to.out, to.slot_stride, to.scratch, to.plane_slot, g.planes_per_image},
-                       g.W, g.H, g.npix, g.pack_tiles, g.color, g.depth, epoch, ticket, g.nplanes};
-    FELICS_LAUNCH((k_pack_fused<T>), dim3(t1 - t0, g.nplanes), dim3(PACK_THREADS), s, planes, k_map, fa, t0);
-}
-template void launch_pack_fused<uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, uint64_t *, uint64_t *, uint32_t *,
-                                         uint64_t *, uint32_t *, uint32_t *, uint32_t *, const PackTarget &,
-                                         const Geometry &, uint32_t, uint32_t, uint32_t, uint32_t *);
-template void launch_pack_fused<int16_t>(hipStream_t, const int16_t *, const uint8_t *, uint64_t *, uint64_t *, uint32_t *,
-                                         uint64_t *, uint32_t *, uint32_t *, uint32_t *, const PackTarget &,
-                                         const Geometry &, uint32_t, uint32_t, uint32_t, uint32_t *);
-
-template <typename T, typename ET>
-void launch_pack_k(hipStream_t s, const T *planes, const ET *sorted_e, const uint32_t *pix_of, const uint32_t *block_state,
-                   const uint32_t *tile_off, const uint32_t *chain_base, const uint32_t *chain_len, uint64_t *status,
-                   uint64_t *tile_bitoff, uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last,
-                   uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t st0, uint32_t st1, uint32_t epoch,
-                   uint32_t *ticket) {
-    if (st1 <= st0) return;
-    const FusedArgs fa{status, tile_bitoff, tile_bits, plane_carry, edge_first, edge_last, error,
-                       PlaneOut{to.out, to.slot_stride, to.scratch, to.plane_slot, g.planes_per_image},
-                       g.W, g.H, g.npix, g.pack_tiles, g.color, g.depth, epoch, ticket, g.nplanes};
-    const KSources ks{sorted_e, reinterpret_cast<const uint16_t *>(pix_of), block_state, tile_off, chain_base, chain_len, g.sort_tiles};
-    FELICS_LAUNCH((k_pack_k<T, ET>), dim3(st1 - st0, g.nplanes), dim3(PACK_THREADS), s, planes, ks, fa, st0, g.pack_tiles);
-}
-template void launch_pack_k<uint8_t, uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, const uint32_t *, const uint32_t *,
-                                              const uint32_t *, const uint32_t *, const uint32_t *, uint64_t *, uint64_t *, uint32_t *,
-                                              uint64_t *, uint32_t *, uint32_t *, uint32_t *, const PackTarget &, const Geometry &,
-                                              uint32_t, uint32_t, uint32_t, uint32_t *);
-template void launch_pack_k<int16_t, uint16_t>(hipStream_t, const int16_t *, const uint16_t *, const uint32_t *, const uint32_t *,
-                                               const uint32_t *, const uint32_t *, const uint32_t *, uint64_t *, uint64_t *, uint32_t *,
-                                               uint64_t *, uint32_t *, uint32_t *, uint32_t *, const PackTarget &, const Geometry &,
-                                               uint32_t, uint32_t, uint32_t, uint32_t *);
-
 template <typename ET>
 void launch_assign_serial(hipStream_t s, const ET *sorted_e, uint8_t *k_sorted, const uint32_t *block_state,
                           const uint32_t *total_slots, const uint32_t *block_tag, const uint32_t *partial, uint32_t epoch,
@@ -2604,6 +2227,12 @@ template void launch_assign_serial<uint8_t>(hipStream_t, const uint8_t *, uint8_
                                             const uint32_t *, const uint32_t *, uint32_t, uint32_t, const Geometry &);
 template void launch_assign_serial<uint16_t>(hipStream_t, const uint16_t *, uint8_t *, const uint32_t *, const uint32_t *,
                                              const uint32_t *, const uint32_t *, uint32_t, uint32_t, const Geometry &);
+
+void launch_k_to_pixels(hipStream_t s, const uint8_t *k_sorted, const uint32_t *pix_of, uint8_t *k_map, const uint32_t *total_slots,
+                         const Geometry &g) {
+    const uint32_t wgs = std::min<uint32_t>(cdiv(max_event_slots(g), 256 * 8), 256u * 8u);
+    FELICS_LAUNCH(k_k_to_pixels, dim3(std::max(wgs, 1u)), dim3(256), s, k_sorted, pix_of, k_map, total_slots);
+}
 
 template <typename T>
 void launch_pack_g(hipStream_t s, const T *planes, const uint8_t *k_sorted, const uint32_t *pix_of, const uint32_t *tile_off,

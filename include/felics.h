@@ -156,10 +156,10 @@ const char *felics_last_error(const felics_ctx *ctx);
  * holding the GPU for a second -- moves the context to the two-pass kernels for good; felics_last_error says so.) */
 typedef struct felics_stats {
     uint64_t submissions;        /* sub-batches queued so far */
-    uint64_t fused_submissions;  /* reserved, always 0 (round 2's opt-in fused tile kernel was measured slower and removed) */
+    uint64_t ticket_retries;     /* 0 or 1: a look-back gave up once and the context now hands its pack tiles out by ticket (first remedy) */
     uint64_t slot_overflows;     /* batches redone with exact placement: a stream outgrew its fixed slot */
     uint64_t lookback_fallbacks; /* batches redone because a tile gave up waiting for its predecessors */
-    int two_pass;                /* 1: the context packs with the two-pass kernels from now on (slower) */
+    int two_pass;                /* 1: a ticketed look-back gave up as well: the context packs with the two-pass kernels from now on (slower) */
     int failed;                  /* 1: a wait for the GPU timed out; every further call returns FELICS_E_HIP */
 } felics_stats;
 int felics_get_stats(const felics_ctx *ctx, felics_stats *out);
@@ -180,8 +180,10 @@ int felics_get_stage_launches(const felics_ctx *ctx, int *launches, int cap);
 /* The same submission from its first kernel to its last byte (stream sizes on the host): one HIP event in front of the first
  * launch, one behind the size copy, on the streams they run on -- BASELINE.md section 2's per-step span. */
 int felics_get_span_ms(const felics_ctx *ctx, float *ms);
-/* Submissions that can be in flight at a time (felics_submit_batch_device). */
+/* Submissions that can be in flight at a time (felics_submit_batch_device): felics_ctx_lane_count for an existing context
+ * (fixed when it was created), felics_lane_count for a context created now (2 unless FELICS_LANES says otherwise). */
 int felics_lane_count(void);
+int felics_ctx_lane_count(const felics_ctx *ctx);
 
 #ifdef __cplusplus
 }

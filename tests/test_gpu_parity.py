@@ -277,11 +277,12 @@ def test_pack_variants(oracle):
 
     frames = [synth.gray8(1920, 1080, f, "S1") for f in range(16)] + [synth.gray8(1920, 1080, 3, "S2")]
     want = [oracle.compress(f) for f in frames]
-    # default: k in chain order from k_assign_serial, gathered by the single-pass pack (k_pack_g); FELICS_ASSIGN=inpack: k
-    # computed inside the single-pass pack (k_pack_k); FELICS_ASSIGN=kernel: separate k_assign kernel + k_map
-    for env in ({}, {"FELICS_ASSIGN": "inpack"}, {"FELICS_ASSIGN": "kernel"}, {"FELICS_TWO_PASS": "1"}, {"FELICS_TEST_LOOKBACK_FAIL": "1"},
-                {"FELICS_ASSIGN": "kernel", "FELICS_TEST_LOOKBACK_FAIL": "1"}, {"FELICS_ASSIGN": "inpack", "FELICS_TEST_LOOKBACK_FAIL": "1"},
-                {"FELICS_OWN_TAILS": "1"}, {"FELICS_LANES": "1"}, {"FELICS_LANES": "4", "FELICS_SLICES": "12"}):
+    # default: k in chain order from k_assign_serial, gathered by the single-pass pack (k_pack_g), tiles by workgroup index;
+    # a look-back that gives up switches to tiles by ticket (what FELICS_OWN_TAILS starts with), a second one to the two-pass
+    # kernels (k to a byte per pixel, lengths, bit scan, pack); FELICS_SERIAL / FELICS_TRACE are the profiling / debugging aids
+    for env in ({}, {"FELICS_TWO_PASS": "1"}, {"FELICS_TEST_LOOKBACK_FAIL": "1"}, {"FELICS_OWN_TAILS": "1"},
+                {"FELICS_OWN_TAILS": "1", "FELICS_TEST_LOOKBACK_FAIL": "1"}, {"FELICS_LANES": "1"}, {"FELICS_LANES": "4", "FELICS_SLICES": "12"},
+                {"FELICS_SERIAL": "1", "FELICS_SLICES": "1"}, {"FELICS_TRACE": "1", "FELICS_TIMEOUT_S": "30"}):
         os.environ.update(env)
         os.environ["FELICS_POISON"] = "1"
         try:
@@ -294,6 +295,12 @@ def test_pack_variants(oracle):
             assert e.compress_batch(frames[:3]) == want[:3], env  # the same context again (after a fallback)
             rgb = [synth.rgb8(640, 360, f) for f in range(3)]
             assert e.compress_batch(rgb) == [oracle.compress(f) for f in rgb], env
+            st = e.stats()
+            if "FELICS_TEST_LOOKBACK_FAIL" in env:  # tickets first (unless the context started with them), then two passes
+                assert st["two_pass"] == 1 and st["lookback_fallbacks"] == (1 if "FELICS_OWN_TAILS" in env else 2), (env, st)
+                assert st["ticket_retries"] == (0 if "FELICS_OWN_TAILS" in env else 1), (env, st)
+            else:
+                assert st["two_pass"] == (1 if "FELICS_TWO_PASS" in env else 0) and st["lookback_fallbacks"] == 0, (env, st)
         finally:
             e.close()
 
@@ -693,10 +700,11 @@ def test_teardown_after_every_lane_was_used(oracle):
         os.environ.update(env)
         try:
             e = felics_amd.Encoder(0)
-            depth_q = int(felics_amd.api.lib().felics_lane_count())
         finally:
             for k in env:
                 del os.environ[k]
+        depth_q = e.lane_count()  # (the context's own count: the environment of a moment ago no longer applies)
+        assert depth_q == int(env.get("FELICS_LANES", 2))
         outs = [torch.zeros(4 * 960 * 540 * 2, dtype=torch.uint8, device="cuda") for _ in range(depth_q)]
         subs = [e.submit_batch_device(d_in.data_ptr(), 4, 960, 540, 0, 0, o.data_ptr(), o.numel()) for o in outs]  # every lane
         for sub, o in zip(subs, outs):

@@ -1428,71 +1428,27 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const T *__restrict__ pla
 }
 
 // ------------------------------------------------------------------------------------------
-// pack, single pass (gray frames with fixed output slots): lengths, bit offsets and packing of a tile
-// in one kernel.
+// pack, single pass (8-bit samples, fixed output slots): lengths, bit offsets and packing of a tile in one kernel.
 //
-// Phase 1: every thread strings the codes of its 16 pixels together into a private LDS buffer
-// (LOCAL_WORDS words; a group with more bits only counts them and is emitted the slow way later).
-// The thread totals are scanned inside the workgroup; the tile's offset in its plane comes from a
-// decoupled look-back over the tiles before it: a tile first publishes its total (AGGREGATE), then
-// wave 0 reads the status words of up to 64 predecessors at a time, adds aggregates until it meets
-// a tile that already knows its inclusive PREFIX, and publishes its own.  A status word is one
-// 64-bit value {epoch, state, bits}, written and read with agent-scope atomics, so it needs no
-// ordering with any other memory; stale words of earlier submissions carry another epoch.
-// Workgroups are dispatched in x-then-y order and a tile only waits for tiles of smaller x in its own
-// row of the grid (or of earlier launches), so everything it waits for has been dispatched; the wait
-// is bounded all the same and reports through `error`.
-// Phase 2: every thread shifts its buffer to its bit offset and ORs it into the LDS window, which
-// is streamed out as in k_pack.  The two words a tile may share with its neighbours go to
-// edge_first / edge_last instead of the output; k_join_edges merges them when all tiles are done,
-// so the output needs no zeroing.
+// Phase A: every thread builds the codes of its 16 pixels -- left-aligned in a register each, with their lengths -- and
+// their total.  The thread totals are scanned inside the workgroup; the tile's offset in its plane comes from a decoupled
+// look-back over the tiles before it: a tile first publishes its total (AGGREGATE), then wave 0 reads the status words of
+// up to 64 predecessors at a time, adds aggregates until it meets a tile that already knows its inclusive PREFIX, and
+// publishes its own.  A status word is one 64-bit value {epoch, state, bits}, written and read with agent-scope atomics, so
+// it needs no ordering with any other memory; stale words of earlier submissions carry another epoch.  A tile only waits
+// for tiles of smaller index in its plane, which have been dispatched (workgroup index) or are running (ticket); the wait is
+// bounded all the same and reports through `error`.
+// Phase B: every thread ORs its sixteen codes into the tile's LDS bit window at their final bit positions (two LDS
+// atomics per code: a code of up to 32 bits touches two words), and the window is streamed out.  The two words a tile may
+// share with its neighbours go to edge_first / edge_last instead of the output; k_join_edges merges them when all tiles
+// are done, so the output needs no zeroing.
+// (Rounds 1-3 strung a thread's codes together in a private LDS buffer first -- a 64-bit window per thread, one store per
+// pixel -- and shifted that string into place afterwards: 14 vector instructions per pixel for the append and 11 for the
+// merge, against 5 here; the codes wait in registers for the tile's offset instead.)
 // ------------------------------------------------------------------------------------------
 
-constexpr uint32_t LOCAL_WORDS = 6;
-constexpr uint32_t FUSED_WIN_WORDS = PACK_TILE * 8 / 32;  // LDS bit window: 8 bits per pixel of a tile in one pass (more bits: more passes)
-// thread-private bit string, MSB-first, word w of thread t at buf[w * PACK_THREADS + t]
-struct LocalBits {
-    uint32_t *buf;
-    uint64_t acc;
-    uint32_t fill, word, total;
+constexpr uint32_t FUSED_WIN_WORDS = PACK_TILE * 16 / 32;  // LDS bit window: 16 bits per pixel of a tile in one pass (more bits: more passes)
 
-    __device__ __forceinline__ void begin(uint32_t *b) {
-        buf = b;
-        acc = 0;
-        fill = word = total = 0;
-    }
-    __device__ __forceinline__ void put(uint32_t v, uint32_t n) {
-        acc |= (uint64_t)v << (64u - fill - n);
-        fill += n;
-        total += n;
-        // The word being filled is stored every time (it is stored for good the time it is complete) and the step to the
-        // next word is arithmetic: a branch here is taken by a few lanes at nearly every pixel, so the whole wave would pay
-        // for it at nearly every pixel.
-        if (word < LOCAL_WORDS) buf[word * PACK_THREADS] = (uint32_t)(acc >> 32);
-        const uint32_t adv = fill >> 5;  // 0 or 1: fill < 64 here
-        acc <<= adv << 5;
-        fill &= 31u;
-        word += adv;
-    }
-    __device__ __forceinline__ void put_ones(uint32_t q) {
-        while (q >= 32 && word < LOCAL_WORDS) {
-            put(0xFFFFFFFFu, 32);
-            q -= 32;
-        }
-        if (q >= 32) {  // past the buffer: only the count matters
-            total += q & ~31u;
-            word += q >> 5;
-            q &= 31u;
-        }
-        if (q) put((1u << q) - 1u, q);
-    }
-    __device__ __forceinline__ void finish() {
-        if (fill && word < LOCAL_WORDS) buf[word * PACK_THREADS] = (uint32_t)(acc >> 32);
-    }
-};
-
-// The single-pass pack of ONE tile by a workgroup (the body of k_pack_g): see the comment above.
-// kq = the tile's k bytes in LDS; they are staged from k_map unless k_map is null (the caller has put them there).
 struct FusedArgs {
     uint64_t *status;
     uint64_t *tile_bitoff;
@@ -1501,11 +1457,10 @@ struct FusedArgs {
     uint32_t *edge_first, *edge_last, *error;
     PlaneOut po;
     uint32_t W, H, npix, ntiles, color, depth, epoch;
-    // Tiles are handed out by a ticket counter (zeroed before the launch) in (tile, plane) order instead of by
-    // blockIdx: a tile only ever waits for tiles with smaller tickets, which are held by workgroups that are already
-    // running, whatever else shares the GPU -- also another pack kernel whose workgroups spin in their own look-back
-    // (with blockIdx two such kernels can hold each other's predecessors out of the CUs: the XCDs dispatch their
-    // shares of a grid independently).
+    // Tiles are handed out by a ticket counter (zeroed before the launch) in (tile, plane) order, or -- null -- by
+    // blockIdx: with tickets a tile only ever waits for tiles held by workgroups that are already running, whatever else
+    // shares the GPU -- also another pack kernel whose workgroups spin in their own look-back (with blockIdx two such
+    // kernels can hold each other's predecessors out of the CUs: the XCDs dispatch their shares of a grid independently).
     uint32_t *ticket;
     uint32_t nplanes;
 };
@@ -1526,16 +1481,13 @@ struct FusedLDS {
 #ifdef FELICS_PACK_STAMPS
     unsigned long long t_last, t_acc[12];
 #endif
-    // lbuf is followed by win: "row LOCAL_WORDS" of lbuf is the first KB of win, which nothing uses while the bit strings
-    // are built -- the row a string's words beyond LOCAL_WORDS are dumped in without a branch (fast_group)
-    uint32_t lbuf[LOCAL_WORDS * PACK_THREADS];
-    uint32_t win[FUSED_WIN_WORDS];
+    uint32_t win[FUSED_WIN_WORDS + 2];  // (+ 1: the second word of a code that starts in the window's last word)
     uint32_t wsum[PACK_THREADS / 64];
     uint64_t tile_lo_sh;
     uint32_t ticket_sh;
 };
 
-// Whether this thread's 16-pixel group takes the branch-free path (fast_group), and what that path needs from outside the
+// Whether this thread's 16-pixel group takes the branch-free path (group_codes), and what that path needs from outside the
 // tile's LDS image: the position of the group's first-column pixel (PACK_PER_THREAD: none) and that pixel's second neighbour
 // (two rows up, or above-right in row 1: misc.rs:14-23).  Computed early by the kernels, so that the one global load is
 // long back when the group is coded.
@@ -1564,83 +1516,223 @@ __device__ __forceinline__ GroupGeom group_geometry(const T *__restrict__ pl, ui
     return gg;
 }
 
-// The bit string of a thread's 16 pixels WITHOUT a branch (the common case): every pixel below the first image row, the
-// group inside the plane.  Same result as walk_group + put_pixel + LocalBits, which stay as the general path (first row,
-// the plane's first two samples and its ragged end, codes longer than 32 bits, images narrower than 16 pixels).
-//   * neighbours: left and above (misc.rs:6-24, interior case).  A first-column pixel takes above and two rows up (above-right
-//     in row 1) instead; the pair is unordered (H = max, L = min), so that rule only replaces the LEFT sample of that one
-//     pixel by `special`, which the caller fetched: the left samples are a byte-shifted copy of the group, patched once.
-//   * both codes of a pixel are built (compression.rs:29-45 + phase_in_coding.rs:59-84 / rice_coding.rs:26-38), one is kept.
-//   * the string is appended to a 64-bit window whose upper word is stored every time (row `word`, clamped to the dump row
-//     behind the thread's LOCAL_WORDS words); it is stored for good the time it is complete.
-// Returns the string's length in bits, or ~0 if a code was longer than 32 bits (the caller then redoes the group).
-template <typename T>
-__device__ __forceinline__ uint32_t fast_group(const TileLDS<T> &t, const uint8_t *kq, uint32_t *lrow, uint32_t j0, int special) {
-    constexpr uint32_t NW = PACK_PER_THREAD * sizeof(T) / 4;  // dwords holding the group's samples
-    constexpr uint32_t PER = 4 / sizeof(T);                    // samples per dword
-    const uint32_t off = threadIdx.x * PACK_PER_THREAD;
-    uint32_t cw[NW], uw[NW], lw[NW], kw[4];
-#pragma unroll
-    for (uint32_t q = 0; q < NW / 4; q++) {
-        const uint4 a = reinterpret_cast<const uint4 *>(t.cur + STAGE_LEAD + off)[q];
-        const uint4 b = reinterpret_cast<const uint4 *>(t.up + off)[q];
-        cw[4 * q] = a.x; cw[4 * q + 1] = a.y; cw[4 * q + 2] = a.z; cw[4 * q + 3] = a.w;
-        uw[4 * q] = b.x; uw[4 * q + 1] = b.y; uw[4 * q + 2] = b.z; uw[4 * q + 3] = b.w;
+// ---- Instruction forms.  profiles/r04/valu_rate.txt: a gfx950 SIMD issues 32-bit add / sub / and / or / xor / lshr / ashr,
+// v_bitop3_b32 and every 16-bit VOP2 instruction (min, max, add, shifts) in 1.0 ns, everything else -- v_min_u32,
+// v_lshlrev_b32, v_cndmask, compares, v_bfe, SDWA / DPP / VOP3 forms, 64-bit shifts -- in 1.7 ns.  The compiler prices them
+// alike and turns sign masks back into compare + select, so the code builder names the cheap forms itself.
+template <uint32_t TABLE>
+__device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TABLE);  // bit i of the result = TABLE[a_i << 2 | b_i << 1 | c_i]
+}
+constexpr uint32_t BT_SEL = 0xE4;      // c ? a : b  =  (a & c) | (b & ~c)
+constexpr uint32_t BT_OR_ANDN = 0xF4;  // a | (b & ~c)
+constexpr uint32_t BT_ANDN = 0x30;     // a & ~b
+__device__ __forceinline__ uint32_t min_u16(uint32_t a, uint32_t b) {  // operands < 2^16
+    uint32_t r;
+    asm("v_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t max_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t twice(uint32_t a) {  // a + a as an add (the compiler would make it a left shift)
+    uint32_t r;
+    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ uint32_t vgpr_const(uint32_t v) {  // a constant kept in a vector register: the shifted operand of v_lshrrev_b32_e32
+    uint32_t r;
+    asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
+    return r;
+}
+
+// Sample j of a group held in packed registers, as an unsigned 16-bit value in an order-preserving offset: u8 samples as
+// they are, i16 samples (Y / Co / Cg planes) with the sign bit flipped -- the codes depend on differences only.
+__device__ __forceinline__ uint32_t field_at(const uint32_t *w, uint32_t j, uint8_t) {
+    const uint32_t x = w[j >> 2];
+    switch (j & 3u) {
+        case 0: return x & 0xFFu;
+        case 1: {
+            uint32_t r;
+            asm("v_lshrrev_b16 %0, 8, %1" : "=v"(r) : "v"(x));  // (low half >> 8, upper half cleared: one cheap instruction)
+            return r;
+        }
+        case 2: return (x >> 16) & 0xFFu;
+        default: return x >> 24;
     }
+}
+__device__ __forceinline__ uint32_t field_at(const uint32_t *w, uint32_t j, int16_t) {
+    const uint32_t x = w[j >> 1] ^ 0x80008000u;
+    return (j & 1u) ? x >> 16 : x & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t field_of(int v, uint8_t) { return (uint32_t)v & 0xFFu; }
+__device__ __forceinline__ uint32_t field_of(int v, int16_t) { return ((uint32_t)v ^ 0x8000u) & 0xFFFFu; }
+
+// One pixel's code, left-aligned in 32 bits, and its length (compression.rs:124-145): p against its two neighbours a, b
+// (unordered; all three in field_at's form), k = the Rice parameter of the pixel's context (used if p is out of range).
+//   in range (L <= p <= H): `1`, then p - L phased-in on n = H - L + 1 values (phase_in_coding.rs:59-84): r = (p - L + P) mod n,
+//       P = 2^m = the largest power of two <= n; r < 2 P - n: r in m bits, else r + 2 P - n in m + 1 bits;
+//   below / above: `00` / `01`, then L - p - 1 / p - H - 1 Rice-coded: q ones, `0`, k low bits (rice_coding.rs:26-38).
+// Both are built and one is kept.  A Rice code longer than 32 bits comes out as garbage with len > 32: the caller redoes
+// such a group the general way.  K31 = 0x80000000, K7F = 0x7FFFFFFF in vector registers (vgpr_const).
+struct PixelCode {
+    uint32_t c32, len;
+};
+__device__ __forceinline__ PixelCode code_pixel(uint32_t p, uint32_t a, uint32_t b, uint32_t k, uint32_t K31, uint32_t K7F) {
+    const uint32_t L = min_u16(a, b), H = max_u16(a, b);
+    const uint32_t ctx = H - L;
+    const int d = (int)(p - L);              // in range: 0 <= d <= ctx
+    const int below = d >> 31;               // all ones: p < L
+    const int o = (int)p - (int)H - 1;       // >= 0: p > H
+    const int not_above = o >> 31;
+    const uint32_t val = bitop3<BT_SEL>((uint32_t)(d ^ below), (uint32_t)o, (uint32_t)not_above);  // ~d = L - p - 1 | d | p - H - 1
+    // phased-in
+    const uint32_t n = ctx + 1u;
+    const uint32_t z = (uint32_t)__builtin_clz(n);  // n >= 1
+    const uint32_t P = K31 >> z;
+    const uint32_t r0 = (uint32_t)d + P, r1 = r0 - n;
+    const uint32_t r = bitop3<BT_SEL>(r0, r1, (uint32_t)((int)r1 >> 31));  // r0 mod n
+    const uint32_t P2 = twice(P), right_p = P2 - n;
+    const int is_short = (int)(r - right_p) >> 31;
+    const uint32_t code_in = r + bitop3<BT_SEL>(P, P2 + right_p, (uint32_t)is_short);  // `1` in front of m or m + 1 bits
+    const uint32_t len_in = (33u - z) + (uint32_t)is_short;                             // m + 1 or m + 2
+    // Rice
+    const uint32_t q = val >> k;
+    const uint32_t ones = K7F >> (31u - q);                                             // q ones (q <= 31)
+    const uint32_t head = bitop3<BT_OR_ANDN>(ones, ones + 1u, (uint32_t)not_above);    // `0` / `1` (above) in front of them
+    const uint32_t rice = bitop3<BT_OR_ANDN>(head << (k + 1u), val, ~0u << k);          // then `0` and the k low bits of val
+    const uint32_t len_rice = q + k + 3u;
+    const uint32_t in_range = bitop3<BT_ANDN>((uint32_t)not_above, (uint32_t)below, 0u);
+    const uint32_t code = bitop3<BT_SEL>(code_in, rice, in_range);
+    PixelCode pc;
+    pc.len = bitop3<BT_SEL>(len_in, len_rice, in_range);
+    pc.c32 = code << (32u - pc.len);
+    return pc;
+}
+
+// The samples a thread's 16-pixel group needs on the branch-free path, straight from memory into registers (the group, the
+// span one row above it, the sample in front of it): coalesced 16-byte loads, a wave reads 1 KB of a row.  The loads are
+// issued at the top of the kernel and first used after the gather of k: their latency hides behind it.
+template <typename T>
+struct GroupSamples {
+    static constexpr uint32_t NW = PACK_PER_THREAD * sizeof(T) / 4;  // dwords holding 16 samples
+    uint32_t cw[NW], uw[NW];
+    int before;
+};
+template <typename T>
+__device__ __forceinline__ void load_group(const T *__restrict__ pl, uint32_t first, uint32_t W, GroupSamples<T> &g) {
+    __builtin_memcpy(g.cw, pl + first, PACK_PER_THREAD * sizeof(T));      // (unaligned when W or the plane's base is odd: the hardware takes it)
+    __builtin_memcpy(g.uw, pl + first - W, PACK_PER_THREAD * sizeof(T));
+    g.before = (int)pl[first - 1];
+}
+
+// The codes of a thread's 16 pixels WITHOUT a branch (the common case): every pixel below the first image row, the group
+// inside the plane.  Same codes as classify + put_pixel, which stay as the general path (first row, the plane's first
+// two samples and its ragged end, codes longer than 32 bits, images narrower than 16 pixels).
+//   * neighbours: left and above (misc.rs:6-24, interior case); the left neighbour of pixel j is pixel j - 1 of the group.
+//   * a first-column pixel (j0) takes above and two rows up (above-right in row 1) instead; the pair is unordered (H = max,
+//     L = min), so that rule only replaces the LEFT sample of that one pixel by `special`, which the caller fetched.  One
+//     thread in 240 has such a pixel: its code is built a second time where a wave holds such a thread.
+// kq = the tile's k bytes in LDS.  Returns the total length in bits (exact also when a code is longer than 32 bits: only
+// that code's c32 is garbage then); longest = the longest code's length.
+template <typename T>
+__device__ __forceinline__ uint32_t group_codes(const GroupSamples<T> &g, const uint8_t *kq, const T *__restrict__ pl, uint32_t first,
+                                                uint32_t W, uint32_t j0, int special, uint32_t (&c32)[PACK_PER_THREAD],
+                                                uint32_t (&len)[PACK_PER_THREAD], uint32_t &longest) {
+    const uint32_t off = threadIdx.x * PACK_PER_THREAD;
+    uint32_t kw[4];
     {
         const uint4 c = *reinterpret_cast<const uint4 *>(kq + off);
         kw[0] = c.x; kw[1] = c.y; kw[2] = c.z; kw[3] = c.w;
     }
-    // left samples: the group shifted up by one sample, the sample in front of the group shifted in
-    const uint32_t before = reinterpret_cast<const uint32_t *>(t.cur + STAGE_LEAD + off)[-1];
-#pragma unroll
-    for (uint32_t q = 0; q < NW; q++) lw[q] = __builtin_amdgcn_alignbyte(cw[q], q ? cw[q - 1] : before, 4 - sizeof(T));
-    if (j0 < PACK_PER_THREAD) {
-        const uint32_t qd = j0 / PER, sh = (j0 % PER) * 8u * sizeof(T);
-        constexpr uint32_t FIELD = sizeof(T) == 1 ? 0xFFu : 0xFFFFu;
-        const uint32_t mask = FIELD << sh, val = ((uint32_t)special & FIELD) << sh;
-#pragma unroll
-        for (uint32_t q = 0; q < NW; q++)
-            if (q == qd) lw[q] = (lw[q] & ~mask) | val;
-    }
-    uint64_t acc = 0;
-    uint32_t room = 64, word = 0, maxlen = 0;  // room = 64 - bits of acc in use (> 32 between pixels)
+    const uint32_t K31 = vgpr_const(0x80000000u), K7F = vgpr_const(0x7FFFFFFFu);
+    uint32_t left = field_of(g.before, T());  // the sample in front of the group
+    longest = 0;
 #pragma unroll
     for (uint32_t j = 0; j < PACK_PER_THREAD; j++) {
-        const int p = sample_at(cw, j, T()), left = sample_at(lw, j, T()), above = sample_at(uw, j, T());
-        const uint32_t k = (kw[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
-        const int H = max(left, above), L = min(left, above);
-        const int d = p - L, ctx = H - L;  // in range: 0 <= d <= ctx
-        const bool below = d < 0, over = d > ctx;
-        uint32_t val = (uint32_t)(d ^ (d >> 31));        // below: L - p - 1 = ~d ; in range: p - L = d
-        val = over ? (uint32_t)(d - ctx - 1) : val;      // above: p - H - 1
-        // phased-in code of d in [0, ctx] (phase_in): r in m bits or r + right_p in m + 1 bits, behind the flag `1`
-        const uint32_t n = (uint32_t)ctx + 1u;
-        const uint32_t m = 31u - (uint32_t)__clz((int)n);
-        const uint32_t right_p = (2u << m) - n;
-        uint32_t r = (uint32_t)d + (1u << m);
-        r = min(r, r - n);  // r -= n if r >= n
-        const bool lt = r < right_p;
-        const uint32_t code_in = (lt ? (1u << m) : (2u << m) + right_p) + r;  // `1`, then the m or m + 1 bits
-        const uint32_t len_in = m + (lt ? 1u : 2u);
-        // Rice code: `00` below / `01` above, q ones, `0`, k-bit remainder (put_pixel)
-        const uint32_t q = val >> k, rem = val & ((1u << k) - 1u);
-        const uint32_t len_rice = q + k + 3u;
-        const uint32_t rice = ((((over ? 1u : 0u) << (q & 31u)) | ((1u << (q & 31u)) - 1u)) << (k + 1u)) | rem;
-        const bool in_range = !(below || over);
-        const uint32_t code = in_range ? code_in : rice, len = in_range ? len_in : len_rice;
-        maxlen = max(maxlen, len);
-        // append
-        room -= len;
-        acc |= (uint64_t)code << (room & 63u);
-        lrow[min(word, LOCAL_WORDS) * PACK_THREADS] = (uint32_t)(acc >> 32);
-        const bool full = room <= 32u;  // the upper word is complete: it has just been stored for good
-        acc = full ? acc << 32 : acc;
-        room = full ? room + 32u : room;
-        word += full ? 1u : 0u;
+        const uint32_t p = field_at(g.cw, j, T());
+        const PixelCode pc = code_pixel(p, left, field_at(g.uw, j, T()), field_at(kw, j, uint8_t()), K31, K7F);
+        c32[j] = pc.c32;
+        len[j] = pc.len;
+        longest = max_u16(longest, pc.len);
+        left = p;
     }
-    if (room < 64u) lrow[min(word, LOCAL_WORDS) * PACK_THREADS] = (uint32_t)(acc >> 32);
-    return maxlen > 32u ? ~0u : word * 32u + (64u - room);
+    if (__ballot(j0 < PACK_PER_THREAD) != 0) {  // (wave-uniform: a quarter of the waves of a 4K plane)
+        if (j0 < PACK_PER_THREAD) {
+            const uint32_t i0 = first + j0;
+            const PixelCode pc = code_pixel(field_of((int)pl[i0], T()), field_of(special, T()), field_of((int)pl[i0 - W], T()),
+                                            (uint32_t)kq[off + j0], K31, K7F);
+#pragma unroll
+            for (uint32_t j = 0; j < PACK_PER_THREAD; j++) {
+                c32[j] = j == j0 ? pc.c32 : c32[j];
+                len[j] = j == j0 ? pc.len : len[j];
+            }
+            longest = max_u16(longest, pc.len);
+        }
+    }
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < PACK_PER_THREAD; j++) total += len[j];
+    return total;
+}
+
+// The general path of a 16-pixel group (first image row, the plane's first two samples and its ragged end, codes longer than
+// 32 bits, images narrower than 16 pixels): the reference's loop as it stands -- neighbour rule (classify: misc.rs:6-24), code
+// lengths / codes (code_length / put_pixel) -- pixel by pixel from global memory, once to count the bits and later once more
+// to build the codes straight into the tile's bit window.  Functions of their own, not inlined: inside the kernel their
+// address arithmetic was hoisted in front of the branch and their registers pushed the common path's sixteen codes into
+// scratch memory.  (kq arrives as a generic pointer into LDS; these paths are rare.)
+struct GeneralGroup {
+    uint32_t tile_first, first, end, W, H, npix, color, depth, has_header;
+};
+template <typename T, typename FR, typename F>
+__device__ __forceinline__ void walk_group_global(const T *__restrict__ pl, const uint8_t *kq, const GeneralGroup &g, FR &&raw, F &&f) {
+    Coord xy;
+    xy.set(g.first, g.W);
+    for (uint32_t i = g.first; i < min(g.end, g.first + PACK_PER_THREAD); i++) {
+        if (i < 2)
+            raw(i, (uint32_t)(int)pl[i]);  // stored as 32-bit values (compression.rs:105-106)
+        else
+            f(classify(pl, i, xy.x, xy.y, g.W), (uint32_t)kq[i - g.tile_first]);
+        xy.advance(1, g.W);
+    }
+}
+template <typename T>
+__device__ __noinline__ uint32_t general_group_bits(const uint8_t *kq, const T *pl, const GeneralGroup g) {
+    uint32_t bits = 0;
+    if (g.first < g.end) {
+        const uint32_t npix = g.npix;
+        if (g.has_header) bits += 8u * 14u;
+        walk_group_global(pl, kq, g, [&](uint32_t, uint32_t) { bits += npix == 1 ? 64u : 32u; },
+                          [&](const PixelClass &pc, uint32_t k) { bits += code_length(pc, k); });
+    }
+    return bits;
+}
+// (the window's word 0 is stream word win_word0; bit 0 of this group is stream bit my_lo)
+template <typename T>
+__device__ __noinline__ void general_group_place(const uint8_t *kq, const T *pl, const GeneralGroup g, uint32_t *win,
+                                                 uint32_t win_words, uint64_t win_word0, uint64_t my_lo) {
+    LaneBits bw;
+    bw.win = win;
+    bw.win_words = win_words;
+    bw.win_word0 = win_word0;
+    bw.begin(my_lo);
+    if (g.has_header) {  // write_header, format.rs:51-61
+        bw.put(0x464C4353u, 32);  // "FLCS"
+        bw.put((g.color << 8) | g.depth, 16);
+        bw.put(g.W, 32);
+        bw.put(g.H, 32);
+    }
+    const uint32_t npix = g.npix;
+    walk_group_global(pl, kq, g,
+                      [&](uint32_t, uint32_t rv) {
+                          bw.put(rv, 32);  // write_signed(32, p): sign-extended sample
+                          if (npix == 1) bw.put(0u, 32);
+                      },
+                      [&](const PixelClass &pc, uint32_t k) { put_pixel(bw, pc, k); });
+    bw.finish();
 }
 
 // this workgroup's (tile offset in the launch, plane)
@@ -1653,25 +1745,82 @@ __device__ __forceinline__ void take_ticket(const FusedArgs &fa, FusedLDS &fl, u
     } else {
         // No counter (launch_pack_g with a null ticket: one-dimensional grid): the workgroup index, in the same (tile, plane)
         // order.  Only for a pack kernel that has the look-back to itself (the lanes share the tail stream): it relies on
-        // workgroups being started in index order; a look-back that waits in vain still gives up and reports through `error`.
+        // workgroups being started in index order; a look-back that waits in vain still gives up and reports through `error`
+        // (the context then switches to tickets: felics_api.cpp, note_lookback_failure).
         t = blockIdx.x;
     }
     x = t / fa.nplanes;
     plane = t - x * fa.nplanes;
 }
 
+// The tile's offset in its plane: decoupled look-back by wave 0 (see the comment above).  Publishes the tile's inclusive
+// prefix, leaves the exclusive one in fl.tile_lo_sh (far beyond any slot if the wait was given up: every store of the tile is
+// then dropped) and, for the last tile of a plane, the plane's size.  The tile's AGGREGATE has been published before.
+__device__ __forceinline__ void look_back(const FusedArgs &fa, FusedLDS &fl, uint32_t tile, uint32_t plane, uint32_t tile_total) {
+    const uint32_t lane = lane_id(), epoch = fa.epoch, ntiles = fa.ntiles;
+    uint64_t *status = fa.status;
+    uint64_t excl = 0;
+    int64_t look = (int64_t)tile - 1;  // tile examined by lane 0
+    uint32_t spins = 0;
+    bool failed = false;
+    while (look >= 0) {
+        const int64_t idx = look - (int64_t)lane;
+        uint32_t state = ST_PREFIX;  // in front of tile 0: prefix 0
+        uint64_t value = 0;
+        if (idx >= 0) {
+            const uint64_t sw = __hip_atomic_load(status + (uint64_t)plane * ntiles + (uint64_t)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t tag = (uint32_t)(sw >> ST_VALUE_BITS);
+            state = (tag >> 2) == (epoch & ST_EPOCH_MASK) ? (tag & 3u) : 0u;
+            value = sw & ((1ull << ST_VALUE_BITS) - 1ull);
+        }
+        const uint64_t pm = __ballot(state == ST_PREFIX), vm = __ballot(state != 0);
+        const uint32_t fp = pm ? (uint32_t)__builtin_ctzll(pm) : 64u;  // nearest tile that knows its prefix
+        const uint64_t need = fp >= 63u ? ~0ull : ((2ull << fp) - 1ull);  // lanes 0..fp must have published
+        if ((vm & need) != need) {
+            if (++spins > LOOKBACK_SPIN_LIMIT) {
+                failed = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        // aggregates of the lanes in front of fp (tile totals, < 2^22 each) and the prefix at fp
+        const uint32_t agg = wave_incl_scan(lane < fp ? (uint32_t)value : 0u);
+        excl += readlane(agg, 63);
+        if (fp < 64u) {
+            excl += ((uint64_t)readlane((uint32_t)(value >> 32), fp) << 32) | readlane((uint32_t)value, fp);
+            break;
+        }
+        look -= 64;
+    }
+    if (failed) {
+        if (lane == 0) atomicOr(fa.error, 1u);
+        excl = ~0ull >> 8;
+    }
+    if (lane == 0) {
+        const uint64_t incl = failed ? 0ull : excl + tile_total;
+        __hip_atomic_store(status + (uint64_t)plane * ntiles + tile, status_word(epoch, ST_PREFIX, incl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fl.tile_lo_sh = excl;
+        if (!failed) {
+            fa.tile_bitoff[(uint64_t)plane * ntiles + tile] = excl;
+            fa.tile_bits[(uint64_t)plane * ntiles + tile] = tile_total;
+            if (tile + 1 == ntiles) {
+                fa.plane_carry[plane] = incl;
+                if (plane % fa.po.planes_per_image != 0 && incl > fa.po.plane_slot * 8u) atomicOr(fa.error, 2u);  // the plane outgrew its scratch slot
+            }
+        }
+    }
+}
+
+// The single-pass pack of ONE tile by a workgroup (the body of k_pack_g): see the comment above.
+// gsm = this thread's samples (valid where gg.fast); kq = the tile's k bytes in LDS and fl.win all zero, with a barrier behind both.
 template <typename T>
-__device__ __forceinline__ void pack_tile_fused(TileLDS<T> &tl, const uint8_t *kq, FusedLDS &fl, const T *__restrict__ planes,
-                                                const uint8_t *__restrict__ k_map, const FusedArgs &fa, uint32_t tile, uint32_t plane,
-                                                const GroupGeom &gg) {
-    uint32_t (&win)[FUSED_WIN_WORDS] = fl.win;
-    uint32_t (&lbuf)[LOCAL_WORDS * PACK_THREADS] = fl.lbuf;
+__device__ __forceinline__ void pack_tile_fused(const GroupSamples<T> &gsm, const uint8_t *kq, FusedLDS &fl, const T *__restrict__ planes,
+                                                const FusedArgs &fa, uint32_t tile, uint32_t plane, const GroupGeom &gg) {
+    uint32_t (&win)[FUSED_WIN_WORDS + 2] = fl.win;
     uint32_t (&wsum)[PACK_THREADS / 64] = fl.wsum;
-    uint64_t &tile_lo_sh = fl.tile_lo_sh;
-    uint64_t *status = fa.status, *tile_bitoff = fa.tile_bitoff, *plane_carry = fa.plane_carry;
-    uint32_t *tile_bits = fa.tile_bits, *edge_first = fa.edge_first, *edge_last = fa.edge_last, *error = fa.error;
     const PlaneOut &po = fa.po;
-    const uint32_t W = fa.W, H = fa.H, npix = fa.npix, ntiles = fa.ntiles, color = fa.color, depth = fa.depth, epoch = fa.epoch;
+    const uint32_t W = fa.W, H = fa.H, npix = fa.npix, ntiles = fa.ntiles;
     const bool first_plane = plane % po.planes_per_image == 0;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const T *pl = planes + (uint64_t)plane * npix;
@@ -1679,41 +1828,23 @@ __device__ __forceinline__ void pack_tile_fused(TileLDS<T> &tl, const uint8_t *k
     const uint32_t first = tile_first + threadIdx.x * PACK_PER_THREAD;
     const uint32_t end = min(tile_first + PACK_TILE, npix);
     const bool has_header = tile == 0 && threadIdx.x == 0 && first_plane;
-    uint64_t *my_status = status + (uint64_t)plane * ntiles + tile;
-
-    if (k_map) {  // (null: the caller has put the pixels and k into LDS, with a barrier behind them)
-        stage_tile(tl, pl, k_map + (uint64_t)plane * npix, tile_first, W, npix);
-        __syncthreads();
-    }
     PSTAMP(4);
 
-    // ---- phase 1: this thread's bit string
+    // ---- phase A: this thread's codes and their total length
     // The branch-free form where it applies: the whole group below the first image row and inside the plane, at most one
     // first-column pixel in it (whose second neighbour -- two rows up, or above-right in row 1 -- comes from global memory).
-    uint32_t fast_bits = ~0u;
-    if (gg.fast) fast_bits = fast_group<T>(tl, kq, lbuf + threadIdx.x, gg.j0, gg.special);
-    LocalBits lb;
-    lb.begin(lbuf + threadIdx.x);
-    lb.total = fast_bits == ~0u ? 0u : fast_bits;
-    if (fast_bits == ~0u && first < end) {
-        if (has_header) {  // write_header, format.rs:51-61
-            lb.put(0x464C4353u, 32);  // "FLCS"
-            lb.put((color << 8) | depth, 16);
-            lb.put(W, 32);
-            lb.put(H, 32);
-        }
-        walk_group(tl, kq, pl, first, end, W,
-                   [&](uint32_t, uint32_t rv) {
-                       lb.put(rv, 32);  // write_signed(32, p): sign-extended sample
-                       if (npix == 1) lb.put(0u, 32);
-                   },
-                   [&](const PixelClass &pc, uint32_t k) { put_pixel(lb, pc, k); });
-        lb.finish();
+    // (The general path is two function calls, placed where none of the common path's codes is in a register: the count in
+    // front of group_codes, the placement behind the common path's.)
+    const GeneralGroup general{tile_first, first, end, W, H, npix, fa.color, fa.depth, has_header ? 1u : 0u};
+    uint32_t bits = 0;
+    if (!gg.fast) bits = general_group_bits<T>(kq, pl, general);  // count now, build the codes straight into the window later
+    uint32_t c32[PACK_PER_THREAD], len[PACK_PER_THREAD];
+    bool in_registers = false;
+    if (gg.fast) {
+        uint32_t longest;
+        bits = group_codes<T>(gsm, kq, pl, first, W, gg.j0, gg.special, c32, len, longest);
+        in_registers = longest <= 32u;  // (a longer code: the lengths stand, the codes are built again the general way)
     }
-    const uint32_t bits = lb.total;
-#if defined(FELICS_PACK_STOP) && FELICS_PACK_STOP == 3
-    if (bits != 0x12345678u) return;  // (the strings are built, nothing is done with them)
-#endif
     const uint32_t inc = wave_incl_scan(bits);
     if (lane == 63) wsum[wave] = inc;
     PSTAMP(5);
@@ -1724,142 +1855,86 @@ __device__ __forceinline__ void pack_tile_fused(TileLDS<T> &tl, const uint8_t *k
         if (w < wave) woff += wsum[w];
         tile_total += wsum[w];
     }
+    if (threadIdx.x == 0)
+        __hip_atomic_store(fa.status + (uint64_t)plane * ntiles + tile, status_word(fa.epoch, ST_AGGREGATE, tile_total), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t my_rel = woff + inc - bits;  // this thread's first bit, from the tile's first bit
 
-    // ---- offset of the tile in its plane: decoupled look-back (wave 0); the others clear the bit window
-    for (uint32_t j = threadIdx.x; j < FUSED_WIN_WORDS; j += PACK_THREADS) win[j] = 0;
-    if (wave == 0) {
-        if (lane == 0)
-            __hip_atomic_store(my_status, status_word(epoch, ST_AGGREGATE, tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint64_t excl = 0;
-        int64_t look = (int64_t)tile - 1;  // tile examined by lane 0
-        uint32_t spins = 0;
-        bool failed = false;
-        while (look >= 0) {
-            const int64_t idx = look - (int64_t)lane;
-            uint32_t state = ST_PREFIX;  // in front of tile 0: prefix 0
-            uint64_t value = 0;
-            if (idx >= 0) {
-                const uint64_t sw = __hip_atomic_load(status + (uint64_t)plane * ntiles + (uint64_t)idx, __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t tag = (uint32_t)(sw >> ST_VALUE_BITS);
-                state = (tag >> 2) == (epoch & ST_EPOCH_MASK) ? (tag & 3u) : 0u;
-                value = sw & ((1ull << ST_VALUE_BITS) - 1ull);
-            }
-            const uint64_t pm = __ballot(state == ST_PREFIX), vm = __ballot(state != 0);
-            const uint32_t fp = pm ? (uint32_t)__builtin_ctzll(pm) : 64u;  // nearest tile that knows its prefix
-            const uint64_t need = fp >= 63u ? ~0ull : ((2ull << fp) - 1ull);  // lanes 0..fp must have published
-            if ((vm & need) != need) {
-                if (++spins > LOOKBACK_SPIN_LIMIT) {
-                    failed = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-                continue;
-            }
-            // aggregates of the lanes in front of fp (tile totals, < 2^22 each) and the prefix at fp
-            const uint32_t agg = wave_incl_scan(lane < fp ? (uint32_t)value : 0u);
-            excl += readlane(agg, 63);
-            if (fp < 64u) {
-                excl += ((uint64_t)readlane((uint32_t)(value >> 32), fp) << 32) | readlane((uint32_t)value, fp);
-                break;
-            }
-            look -= 64;
-        }
-        if (failed) {
-            if (lane == 0) atomicOr(error, 1u);
-            excl = ~0ull >> 8;  // far beyond any slot: every store of this tile is dropped
-        }
-        if (lane == 0) {
-            const uint64_t incl = failed ? 0ull : excl + tile_total;
-            __hip_atomic_store(my_status, status_word(epoch, ST_PREFIX, incl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tile_lo_sh = excl;
-            if (!failed) {
-                tile_bitoff[(uint64_t)plane * ntiles + tile] = excl;
-                tile_bits[(uint64_t)plane * ntiles + tile] = tile_total;
-                if (tile + 1 == ntiles) {
-                    plane_carry[plane] = incl;
-                    if (!first_plane && incl > po.plane_slot * 8u) atomicOr(error, 2u);  // the plane outgrew its scratch slot
-                }
-            }
-        }
-    }
-    __syncthreads();
-    PSTAMP(7);
-#if defined(FELICS_PACK_STOP) && FELICS_PACK_STOP == 4
-    return;
-#endif
-    const uint64_t tile_lo = tile_lo_sh, tile_hi = tile_lo + tile_total;
-    const uint64_t my_lo = tile_lo + woff + inc - bits;
-    uint64_t limit_words;  // a stream that outgrows its slot is cut (the host re-packs)
-    uint32_t *out_words = plane_words(po, plane, limit_words);
-    if (tile_total == 0) return;
-    const uint64_t first_word = tile_lo >> 5, last_word = (tile_hi - 1) >> 5;
-    const bool first_shared = (tile_lo & 31u) != 0, last_shared = (tile_hi & 31u) != 0;
-    const bool overflowed = bits > LOCAL_WORDS * 32u;
-
-    // ---- phase 2: window by window.  Word indices are kept relative to the tile's first word (32 bits: a tile has fewer
-    // than 2^22 bits); the common case is one window and a string inside the thread's LOCAL_WORDS words, whose shifted words
-    // go out in a fixed number of predicated steps (no loop, no branch per word).
-    const uint32_t nwords = (uint32_t)(last_word - first_word) + 1u;                       // words the tile touches
-    const uint32_t my_rel = (uint32_t)(tile_lo & 31u) + woff + inc - bits;                  // this thread's first bit, from the tile's first word
-    uint32_t *out_rel = out_words + first_word;                                              // (only dereferenced below limit_words)
-    const uint32_t limit_rel = limit_words > first_word ? (uint32_t)std::min<uint64_t>(limit_words - first_word, 0xFFFFFFFFull) : 0u;
-    for (uint32_t wb = 0; wb < nwords; wb += FUSED_WIN_WORDS) {
-        if (wb != 0) {  // (the first window was cleared above)
-            __syncthreads();
-            for (uint32_t j = threadIdx.x; j < FUSED_WIN_WORDS; j += PACK_THREADS) win[j] = 0;
-            __syncthreads();
-        }
-        if (!overflowed) {
-            const uint32_t shift = my_rel & 31u, nsrc = (bits + 31u) >> 5;
-            const uint32_t rel0 = (my_rel >> 5) - wb;  // (wraps below the window: the unsigned compare drops it)
-            uint32_t prev = 0;
-#pragma unroll
-            for (uint32_t sidx = 0; sidx <= LOCAL_WORDS; sidx++) {
-                const uint32_t cur = sidx < nsrc ? lbuf[sidx * PACK_THREADS + threadIdx.x] : 0u;
-                const uint32_t v = (uint32_t)((((uint64_t)prev << 32) | cur) >> shift);
-                prev = cur;
-                if (v != 0 && rel0 + sidx < FUSED_WIN_WORDS) atomicOr(&win[rel0 + sidx], v);
-            }
-        } else if (((my_rel + bits - 1) >> 5) >= wb && (my_rel >> 5) < wb + FUSED_WIN_WORDS) {
-            // more bits than the private buffer holds: build the codes again, straight into the window
-            LaneBits bw;
-            bw.win = win;
-            bw.win_words = FUSED_WIN_WORDS;
-            bw.win_word0 = first_word + wb;
-            bw.begin(my_lo);
-            if (has_header) {
-                bw.put(0x464C4353u, 32);
-                bw.put((color << 8) | depth, 16);
-                bw.put(W, 32);
-                bw.put(H, 32);
-            }
-            walk_group(tl, kq, pl, first, end, W,
-                       [&](uint32_t, uint32_t rv) {
-                           bw.put(rv, 32);
-                           if (npix == 1) bw.put(0u, 32);
-                       },
-                       [&](const PixelClass &pc, uint32_t k) { put_pixel(bw, pc, k); });
-            bw.finish();
-        }
-        __syncthreads();
-        // plain stores for the words the tile has to itself: r in [lo, hi) -- one compare per word; the tile's first and last
-        // word, where they are shared with its neighbours, go to the edge arrays (k_join_edges) by thread 0 afterwards
+    // The output words of the tile: word r (from the stream word the tile starts in) = window bits 32 r - s .. 32 r - s + 31,
+    // s = the tile's bit position in that word, known after the look-back.  Plain stores for the words the tile has to itself;
+    // its first and last word, where they are shared with its neighbours, go to the edge arrays (k_join_edges).
+    auto flush_window = [&](uint32_t wb, uint32_t s, uint64_t tile_lo) {
+        const uint64_t tile_hi = tile_lo + tile_total;
+        uint64_t limit_words;  // a stream that outgrows its slot is cut (the host re-packs)
+        uint32_t *out_words = plane_words(po, plane, limit_words);
+        const uint64_t first_word = tile_lo >> 5, last_word = (tile_hi - 1) >> 5;
+        const bool first_shared = (tile_lo & 31u) != 0, last_shared = (tile_hi & 31u) != 0;
+        const uint32_t nwords = (uint32_t)(last_word - first_word) + 1u;  // words the tile touches
+        uint32_t *out_rel = out_words + first_word;                         // (only dereferenced below limit_words)
+        const uint32_t limit_rel = limit_words > first_word ? (uint32_t)std::min<uint64_t>(limit_words - first_word, 0xFFFFFFFFull) : 0u;
         const uint32_t lo = first_shared ? 1u : 0u;
         const uint32_t hi = min(nwords - (last_shared ? 1u : 0u), limit_rel);
         const uint32_t span = hi > lo ? hi - lo : 0u;
+        auto word = [&](uint32_t j) { return __builtin_amdgcn_alignbit(j ? win[j - 1] : 0u, win[j], s); };  // (s = 0: win[j])
 #pragma unroll
         for (uint32_t u = 0; u < FUSED_WIN_WORDS / PACK_THREADS; u++) {
             const uint32_t j = threadIdx.x + u * PACK_THREADS, r = wb + j;  // word r of the tile
-            if (r - lo < span) out_rel[r] = __builtin_bswap32(win[j]);
+            if (r - lo < span) out_rel[r] = __builtin_bswap32(word(j));
         }
         if (threadIdx.x == 0) {
-            if (wb == 0 && first_shared) edge_first[(uint64_t)plane * ntiles + tile] = win[0];  // merged with the previous tile's last word later
+            if (wb == 0 && first_shared) fa.edge_first[(uint64_t)plane * ntiles + tile] = word(0);  // merged with the previous tile's last word later
             const uint32_t rl = nwords - 1u;
-            if (last_shared && !(rl == 0 && first_shared) && rl >= wb && rl - wb < FUSED_WIN_WORDS) edge_last[(uint64_t)plane * ntiles + tile] = win[rl - wb];
+            if (last_shared && !(rl == 0 && first_shared) && rl >= wb && rl - wb < FUSED_WIN_WORDS) fa.edge_last[(uint64_t)plane * ntiles + tile] = word(rl - wb);
+        }
+    };
+    if (tile_total <= (FUSED_WIN_WORDS - 1u) * 32u) {
+        // ---- phase B, the common case: the whole tile in one window, placed from the tile's first bit -- which needs nothing
+        // from other tiles, so the look-back comes behind it, when the tiles in front have long published.  Code j at bit `at`:
+        // its upper part into word at >> 5, what is left of it into the next word (zero if the code ends in the first one; an
+        // LDS OR of zero is cheaper than a branch around it).
+        if (in_registers) {
+            uint32_t at = my_rel;
+            char *wbytes = reinterpret_cast<char *>(win);
+#pragma unroll
+            for (uint32_t j = 0; j < PACK_PER_THREAD; j++) {
+                const uint32_t hi = c32[j] >> (at & 31u), lo = __builtin_amdgcn_alignbit(c32[j], 0u, at & 31u);
+                uint32_t *w2 = reinterpret_cast<uint32_t *>(wbytes + ((at >> 3) & ~3u));
+                atomicOr(w2, hi);
+                atomicOr(w2 + 1, lo);
+                at += len[j];
+            }
+        }
+        if (!in_registers && bits != 0) general_group_place<T>(kq, pl, general, win, FUSED_WIN_WORDS, 0, my_rel);
+        PSTAMP(8);
+        if (wave == 0) look_back(fa, fl, tile, plane, tile_total);
+        __syncthreads();
+        PSTAMP(7);
+        if (tile_total == 0) return;
+        const uint64_t tile_lo = fl.tile_lo_sh;
+        flush_window(0, (uint32_t)(tile_lo & 31u), tile_lo);
+        PSTAMP(1);
+    } else {
+        // more than 16 bits per pixel (no image content does that; a tile of the first rows of a noisy 16 x N image can): several
+        // windows at their final alignment, every thread builds its codes again, the general way, into each window its bits touch
+        if (wave == 0) look_back(fa, fl, tile, plane, tile_total);
+        __syncthreads();
+        const uint64_t tile_lo = fl.tile_lo_sh, my_lo = tile_lo + my_rel;
+        const uint64_t first_word = tile_lo >> 5;
+        const uint32_t nwords = (uint32_t)(((tile_lo + tile_total - 1) >> 5) - first_word) + 1u;
+        const uint32_t my_first = (uint32_t)((my_lo >> 5) - first_word), my_last = (uint32_t)(((my_lo + bits - 1) >> 5) - first_word);
+#pragma nounroll
+        for (uint32_t wb = 0; wb < nwords; wb += FUSED_WIN_WORDS) {
+            if (wb != 0) {  // (the first window arrives cleared)
+                __syncthreads();
+                for (uint32_t j = threadIdx.x; j < FUSED_WIN_WORDS + 2; j += PACK_THREADS) win[j] = 0;
+                __syncthreads();
+            }
+            if (bits != 0 && my_last >= wb && my_first < wb + FUSED_WIN_WORDS)
+                general_group_place<T>(kq, pl, general, win, FUSED_WIN_WORDS, first_word + wb, my_lo);
+            __syncthreads();
+            flush_window(wb, 0u, tile_lo);
         }
     }
-    PSTAMP(8);
 #ifdef FELICS_PACK_STAMPS
     if (threadIdx.x == 0) {
         unsigned long long *slot = g_pack_stamps[(tile * 7u + plane) & 255u];
@@ -1886,8 +1961,9 @@ extern "C" __attribute__((visibility("default"))) int felics_debug_pack_stamps(u
 // chain (tile_off[t][c] .. tile_off[t + 1][c]), and pix_of[slot] is the event's pixel as an offset into the tile.  The
 // workgroup reads its runs -- coalesced: a run is contiguous -- and drops k into the LDS array the pack stage indexes by
 // pixel.  Nothing else of the estimator is left in this kernel.
-// Long runs (more than 32 events) are read 64 events per wave step, up to four steps in flight; short runs one run per
-// lane (a noisy tile has a few hundred runs of a handful of events each).
+// Memory round trips of a tile, in order: {the run table, the thread's own pixels, straight into registers} -> {k and pixel
+// offsets of the runs} -> (codes, placement) -> {the status words of the tiles in front}.  Rounds 1-3 staged the pixels and
+// the run table through LDS behind a barrier of their own and waited for the look-back in front of the placement.
 // ------------------------------------------------------------------------------------------
 
 struct GSources {
@@ -1900,10 +1976,9 @@ struct GSources {
 template <typename T>
 __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 5))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_g(const T *__restrict__ planes, GSources gs, FusedArgs fa,
                                                                                                uint32_t sort_tile_begin, uint32_t pack_tile_end) {
-    __shared__ TileLDS<T> tl;
+    __shared__ alignas(16) uint8_t kq[PACK_TILE];  // k of pixel tile_first + j (event pixels only: the others hold what was there)
     __shared__ FusedLDS fl;
     static_assert(SORT_TILE == PACK_TILE, "one workgroup = one sort tile = one pack tile (one look-back per workgroup)");
-    uint8_t *kq = tl.kq;
     uint32_t x, plane;
 #ifdef FELICS_PACK_STAMPS
     if (threadIdx.x == 0) {
@@ -1919,11 +1994,12 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 5))) __global__ __launch
     constexpr uint32_t NWV = PACK_THREADS / 64;
     constexpr uint32_t NC = nctx_of<T>();
     constexpr uint32_t CPT = NC / PACK_THREADS;  // contexts per thread
-    static_assert(NC == CPT * PACK_THREADS, "thread t loads the runs of contexts t, t + PACK_THREADS, ...");
-    const GroupGeom gg = group_geometry<T>(planes + (uint64_t)plane * fa.npix, st, fa.W, fa.npix);
-    static_assert(2 * NC <= FUSED_WIN_WORDS + LOCAL_WORDS * PACK_THREADS && offsetof(FusedLDS, win) == offsetof(FusedLDS, lbuf) + sizeof(fl.lbuf),
-                  "the run table borrows lbuf + win (used by the pack stage only afterwards)");
-    uint32_t *run_a = fl.lbuf, *run_n = fl.lbuf + NC;  // first slot / events of the tile's run in context c
+    static_assert(NC == CPT * PACK_THREADS, "every thread takes CPT contexts");
+    const T *pl = planes + (uint64_t)plane * fa.npix;
+    // ---- round trip 1: the runs of this thread's contexts and its pixels.  Wave w takes contexts w, w + 4, w + 8, ... (lane l:
+    // context 4 l + w, + 256 for the second half of a Y / Co / Cg table): the contexts that matter in a smooth frame are the
+    // first ten, and this way every wave gets its share of them.
+    uint32_t run_a[CPT], run_n[CPT];
     {
         const uint32_t *off0 = gs.tile_off + ((uint64_t)plane * gs.sort_ntiles + st) * NC;
         const bool last_tile = st + 1 == gs.sort_ntiles;
@@ -1932,35 +2008,29 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 5))) __global__ __launch
         uint32_t ra[CPT], rb[CPT], rbase[CPT];
 #pragma unroll
         for (uint32_t h = 0; h < CPT; h++) {
-            const uint32_t c = threadIdx.x + h * PACK_THREADS;
+            const uint32_t c = h * PACK_THREADS + lane * NWV + wave;
             ra[h] = off0[c];
             rb[h] = off1[c];
             rbase[h] = cb[c];
         }
-        // the tile's pixels come in on the same round trip as the run table
-        stage_pixels(tl, planes + (uint64_t)plane * fa.npix, st * PACK_TILE, fa.W, fa.npix);
 #pragma unroll
         for (uint32_t h = 0; h < CPT; h++) {
-            const uint32_t c = threadIdx.x + h * PACK_THREADS;
-            run_a[c] = ra[h] + rbase[h];
-            run_n[c] = rb[h] - ra[h];
+            run_a[h] = ra[h] + rbase[h];  // first slot of the tile's run in context c
+            run_n[h] = rb[h] - ra[h];     // its events
         }
     }
+    const GroupGeom gg = group_geometry<T>(pl, st, fa.W, fa.npix);
+    GroupSamples<T> gsm;
+    if (gg.fast) load_group(pl, st * PACK_TILE + threadIdx.x * PACK_PER_THREAD, fa.W, gsm);
+    for (uint32_t j = threadIdx.x; j < FUSED_WIN_WORDS + 2; j += PACK_THREADS) fl.win[j] = 0;  // the bit window (barrier: behind the gather)
     PSTAMP(9);
-#if defined(FELICS_PACK_STOP) && FELICS_PACK_STOP == 1
-    return;  // (diagnostic builds: instruction counts of the kernel's stages, profiles/tools/pack_stages.sh)
-#endif
-    __syncthreads();
-    PSTAMP(10);
-    // wave w takes contexts w, w + 4, w + 8, ...: the contexts that matter in a smooth frame are the first ten.
-    // Runs of up to GATHER_SHORT events are read one run per lane, all of them at once; longer runs 64 events per
-    // wave-load, GATHER_CHUNKS such loads (of any of the wave's runs) in flight together: the stage is one or two memory
-    // round trips per tile, not one per run.
+    // ---- round trip 2: k and pixel offsets through the runs.  Runs of up to GATHER_SHORT events are read one run per lane,
+    // all of them at once; longer runs 64 events per wave-load, GATHER_CHUNKS such loads (of any of the wave's runs) in flight
+    // together.
     constexpr uint32_t GATHER_SHORT = 8, GATHER_CHUNKS = 8;
 #pragma unroll
-    for (uint32_t h = 0; h < NC / (64 * NWV); h++) {
-        const uint32_t c = h * 64 * NWV + lane * NWV + wave;
-        const uint32_t a = run_a[c], n = run_n[c];
+    for (uint32_t h = 0; h < CPT; h++) {
+        const uint32_t a = run_a[h], n = run_n[h];
         // (Loads and LDS stores are not predicated lane by lane: a lane past the end of its run / chunk takes the last element
         // again -- the same k goes to the same pixel twice -- so a whole group of loads runs under ONE condition; lane-wise
         // predicates were four scalar instructions per load, 140 M scalar instructions per step in this stage.)
@@ -2002,12 +2072,9 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 5))) __global__ __launch
         }
     }
     PSTAMP(2);
-#if defined(FELICS_PACK_STOP) && FELICS_PACK_STOP == 2
-    return;
-#endif
     __syncthreads();
     PSTAMP(3);
-    if (st < pack_tile_end) pack_tile_fused<T>(tl, kq, fl, planes, nullptr, fa, st, plane, gg);
+    if (st < pack_tile_end) pack_tile_fused<T>(gsm, kq, fl, planes, fa, st, plane, gg);
 }
 
 // Words shared by two tiles (and the last, partly filled word of a plane): OR of the two halves.

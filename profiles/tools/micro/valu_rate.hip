@@ -126,10 +126,19 @@
   X(96, "v_subrev_u32", "v_subrev_u32 %0, %0, %10\nv_subrev_u32 %1, %1, %10\nv_subrev_u32 %2, %2, %10\nv_subrev_u32 %3, %3, %10\nv_subrev_u32 %4, %4, %10\nv_subrev_u32 %5, %5, %10\nv_subrev_u32 %6, %6, %10\nv_subrev_u32 %7, %7, %10\n") \
   X(97, "v_xnor_b32", "v_xnor_b32 %0, %0, %10\nv_xnor_b32 %1, %1, %10\nv_xnor_b32 %2, %2, %10\nv_xnor_b32 %3, %3, %10\nv_xnor_b32 %4, %4, %10\nv_xnor_b32 %5, %5, %10\nv_xnor_b32 %6, %6, %10\nv_xnor_b32 %7, %7, %10\n") \
   X(98, "v_add_co_u32", "v_add_co_u32 %0, vcc, %0, %10\nv_add_co_u32 %1, vcc, %1, %10\nv_add_co_u32 %2, vcc, %2, %10\nv_add_co_u32 %3, vcc, %3, %10\nv_add_co_u32 %4, vcc, %4, %10\nv_add_co_u32 %5, vcc, %5, %10\nv_add_co_u32 %6, vcc, %6, %10\nv_add_co_u32 %7, vcc, %7, %10\n") \
-  X(99, "v_lshlrev_b32 + v_add_u32 interleaved (per pair)", "v_lshlrev_b32 %0, %10, %0\nv_add_u32 %0, %0, %10\nv_lshlrev_b32 %1, %10, %1\nv_add_u32 %1, %1, %10\nv_lshlrev_b32 %2, %10, %2\nv_add_u32 %2, %2, %10\nv_lshlrev_b32 %3, %10, %3\nv_add_u32 %3, %3, %10\nv_lshlrev_b32 %4, %10, %4\nv_add_u32 %4, %4, %10\nv_lshlrev_b32 %5, %10, %5\nv_add_u32 %5, %5, %10\nv_lshlrev_b32 %6, %10, %6\nv_add_u32 %6, %6, %10\nv_lshlrev_b32 %7, %10, %7\nv_add_u32 %7, %7, %10\n")
+  X(99, "v_lshlrev_b32 + v_add_u32 interleaved (per pair)", "v_lshlrev_b32 %0, %10, %0\nv_add_u32 %0, %0, %10\nv_lshlrev_b32 %1, %10, %1\nv_add_u32 %1, %1, %10\nv_lshlrev_b32 %2, %10, %2\nv_add_u32 %2, %2, %10\nv_lshlrev_b32 %3, %10, %3\nv_add_u32 %3, %3, %10\nv_lshlrev_b32 %4, %10, %4\nv_add_u32 %4, %4, %10\nv_lshlrev_b32 %5, %10, %5\nv_add_u32 %5, %5, %10\nv_lshlrev_b32 %6, %10, %6\nv_add_u32 %6, %6, %10\nv_lshlrev_b32 %7, %10, %7\nv_add_u32 %7, %7, %10\n") \
+  X(100, "mix c e c e c e c e (add/min, independent; per 8)", "v_add_u32 %0, %0, %10\nv_min_u32 %1, %1, %10\nv_add_u32 %2, %2, %10\nv_min_u32 %3, %3, %10\nv_add_u32 %4, %4, %10\nv_min_u32 %5, %5, %10\nv_add_u32 %6, %6, %10\nv_min_u32 %7, %7, %10\n") \
+  X(101, "mix c c e e c c e e (per 8)", "v_add_u32 %0, %0, %10\nv_add_u32 %1, %1, %10\nv_min_u32 %2, %2, %10\nv_min_u32 %3, %3, %10\nv_add_u32 %4, %4, %10\nv_add_u32 %5, %5, %10\nv_min_u32 %6, %6, %10\nv_min_u32 %7, %7, %10\n") \
+  X(102, "mix c c c c e e e e (per 8)", "v_add_u32 %0, %0, %10\nv_add_u32 %1, %1, %10\nv_add_u32 %2, %2, %10\nv_add_u32 %3, %3, %10\nv_min_u32 %4, %4, %10\nv_min_u32 %5, %5, %10\nv_min_u32 %6, %6, %10\nv_min_u32 %7, %7, %10\n") \
+  X(103, "mix c c c e c c c e (per 8)", "v_add_u32 %0, %0, %10\nv_add_u32 %1, %1, %10\nv_add_u32 %2, %2, %10\nv_min_u32 %3, %3, %10\nv_add_u32 %4, %4, %10\nv_add_u32 %5, %5, %10\nv_add_u32 %6, %6, %10\nv_min_u32 %7, %7, %10\n") \
+  X(104, "mix c c c c c c c e (per 8)", "v_add_u32 %0, %0, %10\nv_add_u32 %1, %1, %10\nv_add_u32 %2, %2, %10\nv_add_u32 %3, %3, %10\nv_add_u32 %4, %4, %10\nv_add_u32 %5, %5, %10\nv_add_u32 %6, %6, %10\nv_min_u32 %7, %7, %10\n") \
+  X(105, "mix add/lshl c L c L c L c L (per 8)", "v_add_u32 %0, %0, %10\nv_lshlrev_b32 %1, %10, %1\nv_add_u32 %2, %2, %10\nv_lshlrev_b32 %3, %10, %3\nv_add_u32 %4, %4, %10\nv_lshlrev_b32 %5, %10, %5\nv_add_u32 %6, %6, %10\nv_lshlrev_b32 %7, %10, %7\n") \
+  X(106, "mix add/bitop3 c b c b c b c b (per 8)", "v_add_u32 %0, %0, %10\nv_bitop3_b32 %1, %1, %10, %11 bitop3:0xe4\nv_add_u32 %2, %2, %10\nv_bitop3_b32 %3, %3, %10, %11 bitop3:0xe4\nv_add_u32 %4, %4, %10\nv_bitop3_b32 %5, %5, %10, %11 bitop3:0xe4\nv_add_u32 %6, %6, %10\nv_bitop3_b32 %7, %7, %10, %11 bitop3:0xe4\n") \
+  X(107, "mix add/min_u16 alternating (per 8)", "v_add_u32 %0, %0, %10\nv_min_u16 %1, %1, %10\nv_add_u32 %2, %2, %10\nv_min_u16 %3, %3, %10\nv_add_u32 %4, %4, %10\nv_min_u16 %5, %5, %10\nv_add_u32 %6, %6, %10\nv_min_u16 %7, %7, %10\n") \
+  X(108, "mix e c c c c c c c x8 dependent chain a0 only: add add add min (per 8)", "v_add_u32 %0, %0, %10\nv_add_u32 %0, %0, %10\nv_add_u32 %0, %0, %10\nv_min_u32 %0, %0, %10\nv_add_u32 %0, %0, %10\nv_add_u32 %0, %0, %10\nv_add_u32 %0, %0, %10\nv_min_u32 %0, %0, %10\n")
 // clang-format on
 
-constexpr int NKINDS = 100;
+constexpr int NKINDS = 109;
 
 template <int KIND>
 __global__ __launch_bounds__(512) void k(unsigned long long *out, unsigned *sink, int iters) {

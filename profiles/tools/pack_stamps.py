@@ -1,14 +1,13 @@
-"""Where a pack workgroup's time goes, phase by phase (s_memtime stamps of thread 0, summed per tile): k_pack_g by default,
-k_pack_k with FELICS_ASSIGN=inpack.
+"""Where a pack workgroup's time goes, phase by phase (s_memtime stamps of thread 0, summed per tile; k_pack_g).
 
 Needs a library built with the stamps compiled in (they are not in the product build):
-    make -C felics_amd/csrc lib OUT=../../scratch/pstamps CXXFLAGS="-O3 -std=c++17 -fPIC -DFELICS_PACK_STAMPS"
-    python profiles/tools/pack_stamps.py 64        # on the GPU box, from the repository root
+    profiles/tools/variant.sh pstamps -DFELICS_PACK_STAMPS       # in the build container
+    python3 profiles/tools/pack_stamps.py 64                     # on the GPU box, from the repository root
 """
 import os, sys, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("FELICS_LIB_PATH", os.path.join(ROOT, "scratch", "pstamps", "libfelics.so"))
+os.environ.setdefault("FELICS_LIB_PATH", os.path.join(ROOT, "felics_amd", "_variants", "pstamps", "libfelics.so"))
 import numpy as np, torch
 import felics_amd
 from felics_amd import synth_torch, api
@@ -32,10 +31,7 @@ dt = (time.time() - t) / R
 lib.felics_debug_pack_stamps(buf, 0)
 a = np.array(list(buf), dtype=np.float64).reshape(256, 16); v = list(a.sum(0))
 cnt = v[15]
-if os.environ.get("FELICS_ASSIGN") == "inpack":
-    names = ["ticket", "items: expansion + barrier", "own assign loop", "wait other waves", "stage pixels", "phase 1 (codes)", "sync", "look-back + sync", "phase 2 (window, stores)", "items: loads + staging", "items: scan + barrier"]
-else:
-    names = ["tile (ticket / workgroup index) + group geometry", "-", "gather k through the runs", "wait for the other waves", "-", "phase 1 (bit strings)", "sync", "look-back + sync", "phase 2 (window, stores)", "run table + pixels: loads, staging", "barrier"]
+names = ["tile (ticket / workgroup index)", "window out (shift, stores)", "gather k through the runs (waits for round trip 1)", "wait for the other waves", "-", "phase A (sixteen codes) + scan", "sync", "look-back + sync", "phase B (codes into the window)", "run table + pixel loads issued, window cleared", "-"]
 print("blocking call %.3f ms; %d tiles stamped; s_memtime ticks per tile (thread 0):" % (dt * 1e3, cnt))
 tot = sum(v[:11])
 for i, nm in enumerate(names):

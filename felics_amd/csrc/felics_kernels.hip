@@ -293,15 +293,24 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
                                                  const uint32_t *__restrict__ chain_base,
                                                  ET *__restrict__ sorted_e, uint32_t *__restrict__ pix_of,
                                                  uint32_t W, uint32_t npix, uint32_t ntiles, uint32_t tile_begin,
-                                                 uint32_t tile_end) {
+                                                 uint32_t tile_end, uint32_t nplanes) {
     constexpr uint32_t RING = 512;  // a trip adds at most 256 events to fewer than 64 left over
     static_assert(RING >= 256 + 64 && (RING & (RING - 1)) == 0, "the ring holds a trip's events behind a partial batch, and is indexed with a mask");
     static_assert(SORT_TILE <= (1u << 13), "ring records keep the pixel's offset in its tile in 13 bits");
     __shared__ uint32_t runs[4][nctx_of<T>()];
     __shared__ uint32_t rings[4][RING];
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();  // (uniform: see k_hist)
-    const uint32_t tile = tile_begin + blockIdx.x * 4 + wave;
-    const uint32_t plane = blockIdx.y;
+    // Workgroup -> (plane, four tiles), XCD-aware: workgroups are dealt round-robin over the eight XCDs (MI355X_MICROARCH.md,
+    // workgroup dispatch: blocks b and b + 8 share one), and every XCD has an L2 of its own that does not merge its partial
+    // lines with another XCD's.  Neighbouring tiles of a plane append to the same cache lines of every chain, so all tiles of
+    // plane p go to the XCD p % 8 (in tile order: workgroup b = 8 i + x takes item i of XCD x's list of planes x, x + 8, ...) --
+    // the XCD whose spine and pack workgroups read the chains of plane p later (their grids are plane-minor with 64 planes).
+    // Placement only: nothing depends on it for correctness.
+    const uint32_t wg_tiles = (tile_end - tile_begin + 3u) / 4u;
+    const uint32_t item = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+    const uint32_t plane = xcd + 8u * (item / wg_tiles);
+    if (plane >= nplanes) return;
+    const uint32_t tile = tile_begin + (item % wg_tiles) * 4 + wave;
     if (tile >= tile_end) return;
     uint32_t *run = runs[wave];
     {
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
         __builtin_amdgcn_wave_barrier();
         if (ev) {
             sorted_e[dest] = (ET)e;
-            if (REL)  // the pack stage that computes k itself knows its tile: two bytes per event instead of four
+            if (REL)  // the pack stage knows its tile: two bytes per event instead of four
                 reinterpret_cast<uint16_t *>(pix_of)[dest] = (uint16_t)off;
             else
                 pix_of[dest] = plane_first + begin + off;
@@ -664,7 +673,10 @@ extern "C" __attribute__((visibility("default"))) int felics_debug_spine_stamps(
 #endif
 
 constexpr uint32_t SP_BATCH = 8;    // blocks per hand-over
-constexpr uint32_t SP_HELPERS = 3;
+#ifndef FELICS_SP_HELPERS
+#define FELICS_SP_HELPERS 3
+#endif
+constexpr uint32_t SP_HELPERS = FELICS_SP_HELPERS;
 constexpr uint32_t SP_SMALL = 24;   // blocks
 
 typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
@@ -676,7 +688,7 @@ __device__ __forceinline__ bool pk_all_ge(uint32_t p, uint32_t theta) {
 }
 
 template <typename ET>
-__global__ __launch_bounds__(256) void k_spine2(const ET *__restrict__ sorted_e, uint32_t *__restrict__ block_state,
+__global__ __launch_bounds__(64 * (1 + SP_HELPERS)) void k_spine2(const ET *__restrict__ sorted_e, uint32_t *__restrict__ block_state,
                                                 const uint32_t *__restrict__ chain_base,
                                                 const uint32_t *__restrict__ chain_len, uint32_t nchains,
                                                 const uint32_t *__restrict__ tile_off, uint32_t ntiles, uint32_t t_end,
@@ -2168,12 +2180,14 @@ template <typename T, typename ET>
 void launch_scatter(hipStream_t s, const T *planes, const uint32_t *tile_off, const uint32_t *chain_base,
                     ET *sorted_e, uint32_t *pix_of, bool in_tile_offsets, const Geometry &g, uint32_t tile_begin, uint32_t tile_end) {
     if (tile_end <= tile_begin) return;
+    // one workgroup per four tiles of a plane; the planes are dealt to the XCDs by the kernel (see there)
+    const dim3 grid(8u * cdiv(g.nplanes, 8) * cdiv(tile_end - tile_begin, 4));
     if (in_tile_offsets)
-        FELICS_LAUNCH((k_scatter<T, ET, true>), dim3(cdiv(tile_end - tile_begin, 4), g.nplanes), dim3(256), s, planes,
-                           tile_off, chain_base, sorted_e, pix_of, g.W, g.npix, g.sort_tiles, tile_begin, tile_end);
+        FELICS_LAUNCH((k_scatter<T, ET, true>), grid, dim3(256), s, planes, tile_off, chain_base, sorted_e, pix_of, g.W, g.npix,
+                      g.sort_tiles, tile_begin, tile_end, g.nplanes);
     else
-        FELICS_LAUNCH((k_scatter<T, ET, false>), dim3(cdiv(tile_end - tile_begin, 4), g.nplanes), dim3(256), s, planes,
-                           tile_off, chain_base, sorted_e, pix_of, g.W, g.npix, g.sort_tiles, tile_begin, tile_end);
+        FELICS_LAUNCH((k_scatter<T, ET, false>), grid, dim3(256), s, planes, tile_off, chain_base, sorted_e, pix_of, g.W, g.npix,
+                      g.sort_tiles, tile_begin, tile_end, g.nplanes);
 }
 template void launch_scatter<uint8_t, uint8_t>(hipStream_t, const uint8_t *, const uint32_t *, const uint32_t *,
                                                uint8_t *, uint32_t *, bool, const Geometry &, uint32_t, uint32_t);
@@ -2197,7 +2211,7 @@ void launch_spine(hipStream_t s, const ET *sorted_e, uint32_t *block_state, cons
                   const uint32_t *chain_len, const uint32_t *tile_off, uint32_t t_end, uint32_t *chain_prog,
                   uint32_t *block_tag, uint32_t *partial, uint32_t epoch, uint32_t slice, const Geometry &g) {
     const uint32_t nchains = g.nplanes * g.nctx;
-    FELICS_LAUNCH((k_spine2<ET>), dim3(nchains), dim3(256), s, sorted_e, block_state, chain_base, chain_len,
+    FELICS_LAUNCH((k_spine2<ET>), dim3(nchains), dim3(64 * (1 + SP_HELPERS)), s, sorted_e, block_state, chain_base, chain_len,
                        nchains, tile_off, g.sort_tiles, t_end, chain_prog, block_tag,
                        reinterpret_cast<uint2 *>(partial) + (uint64_t)(slice - 1) * nchains,
                        (epoch << TAG_SLICE_BITS) | slice);

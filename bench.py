@@ -239,6 +239,10 @@ def main():
     group.barrier()
     elapsed = time.perf_counter() - t0
     enc.set_profiling(False)
+    # every rank's own figures (skew between ranks, and which device each one ran on), gathered before the MAX
+    per_rank = group.gather_objects({"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(local),
+                                     "device_index": local, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
+                                     "frames": F, "first_frame": first_frame})
     elapsed = group.max_over_ranks(elapsed)
 
     # the timed steps must have produced the same bytes as the checked one (both output buffers)
@@ -316,6 +320,49 @@ def main():
                                                    "byte_compared_with_oracle": True,
                                                    "note": "one GPU's share of config 5 (512 frames over 8 GPUs); --config 5 --gpus N times the sharded job"}
         del rgbf, outs5
+        # 16-bit samples (traits.rs:35-43: half of the trait's surface) ride along as well: 16 4K gray16 frames per submission on a
+        # context of its own with four submissions in flight (the 16-bit kernels wait for memory more than for the ALUs:
+        # profiles/r03/experiments.txt), one stream byte-compared with the oracle, three timed steps.
+        from felics_amd import synth
+
+        F16 = 16
+        base16 = [torch.from_numpy(synth.gray16(W, H, first_frame + i).view(np.int16)) for i in range(4)]
+        fr16 = torch.stack([base16[i % 4] for i in range(F16)]).to(dev)
+        os.environ["FELICS_LANES"] = "4"
+        try:
+            enc16 = felics_amd.Encoder(local)
+        finally:
+            del os.environ["FELICS_LANES"]
+        q16 = enc16.lane_count()
+        outs16 = [torch.empty(int(F16 * npix * 2 * 1.25) + (1 << 20), dtype=torch.uint8, device=dev) for _ in range(q16)]
+        o16, l16 = enc16.compress_batch_device(fr16.data_ptr(), F16, W, H, 0, 1, outs16[0].data_ptr(), outs16[0].numel())
+        got = outs16[0][int(o16[1]): int(o16[1] + l16[1])].cpu().numpy().tobytes()
+        if got != oracle.compress(fr16[1].cpu().numpy().view(np.uint16)):
+            raise SystemExit("16-bit leg: GPU stream differs from the oracle")
+        for i in range(q16):  # every lane's workspace
+            enc16.wait_batch(enc16.submit_batch_device(fr16.data_ptr(), F16, W, H, 0, 1, outs16[i].data_ptr(), outs16[i].numel()))
+        reps16 = 8
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        q = []
+        for i in range(reps16):
+            if len(q) == q16:
+                enc16.wait_batch(q.pop(0))
+            q.append(enc16.submit_batch_device(fr16.data_ptr(), F16, W, H, 0, 1, outs16[i % q16].data_ptr(), outs16[i % q16].numel()))
+        while q:
+            enc16.wait_batch(q.pop(0))
+        t16 = (time.perf_counter() - t1) / reps16
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            enc16.compress_batch_device(fr16.data_ptr(), F16, W, H, 0, 1, outs16[0].data_ptr(), outs16[0].numel())
+        b16 = (time.perf_counter() - t1) / 3
+        side["gray16_16_4k_frames"] = {"ms_per_step_queued": round(t16 * 1e3, 3), "ms_per_blocking_call": round(b16 * 1e3, 3),
+                                       "MPix_s": round(F16 * npix / t16 / 1e6, 1), "frac_of_hbm_peak": round(F16 * npix * 2 / t16 / 1e9 / HBM_PEAK_GBS, 5),
+                                       "submissions_in_flight": q16, "steps": reps16, "dtype": "u16", "byte_compared_with_oracle": True,
+                                       "note": "16 synthetic 4K gray16 frames per step (2 B per pixel against the HBM-read roofline); not the headline"}
+        enc16.close()
+        del fr16, outs16
     # Decode, for the record: the batch's streams through the GPU decoder (one wave per stream: the
     # format is bit-serial per stream) and a sample of them through the host decoder on this box's cores.
     decode = None
@@ -403,8 +450,15 @@ def main():
                     if insts:  # wave64 VALU instructions per step against 1024 SIMDs x 2.4 GHz / 2 cycles per instruction
                         # the chip's sustained rate of wave64 integer VALU instructions, measured (profiles/tools/micro/valu_rate.hip,
                         # profiles/r03/valu_rate.txt: 1.71-1.73 ns per instruction and SIMD with every SIMD issuing), not a data-sheet figure
-                        valu = {"wave_insts_per_step": int(insts), "issue_peak_per_s": 0.595e12, "issue_peak": "measured, profiles/r03/valu_rate.txt",
-                                "frac_of_issue_peak": round(insts / 0.595e12 / (ms_per_step * 1e-3), 4)}
+                        # the step's vector instructions priced by class (profiles/r04/valu_rate.txt: 1.0 ns per wave64 instruction and SIMD for
+                        # add / sub / logic / shift-right / bitop3 / 16-bit VOP2, 1.7 ns for the rest; profiles/r04/opcodes.txt: each kernel's
+                        # share of cheap instructions from the shipped code object) -- an additive figure: mixed streams cost more
+                        # (valu_rate_mixed_streams.txt), so it is a lower bound of the issue time
+                        weighted_ns = tj.get("_valu_weighted_ns_per_step")
+                        valu = {"wave_insts_per_step": int(insts), "issue_peak_per_s": 0.595e12, "issue_peak": "measured, profiles/r04/valu_rate.txt (1.7 ns class)",
+                                "frac_of_issue_peak": round(insts / 0.595e12 / (ms_per_step * 1e-3), 4),
+                                "weighted_issue_ms_per_step": None if not weighted_ns else round(weighted_ns / 1024 / 1e6, 4),
+                                "weighted_frac_of_step": None if not weighted_ns else round(weighted_ns / 1024 / 1e6 / ms_per_step, 4)}
             roofline = {"bound": "hbm", "kernel": kernel_of(dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(per_launch_ms, 4),
@@ -417,6 +471,17 @@ def main():
                     by_kernel[kernel_of(k)] = {"ms_per_step_sum_of_launches": round(v, 4), "launches_per_step": n,
                                                "achieved_GBs": round(g, 2), "frac": round(g / HBM_PEAK_GBS, 5)}
             roofline["by_kernel"] = by_kernel
+            # Two readings of "dominant".  The largest SUM of launch durations is the spine: a latency chain of a few hundred waves that
+            # runs underneath the others, with as many of its launches side by side as there are submissions in flight -- so its
+            # launches can sum to more than ms_per_step.  The largest kernel that FILLS the GPU is the one to read a share of the
+            # machine from.
+            roofline["latency_chain_kernel"] = {"kernel": kernel_of("spine"), "concurrent_launches": depth_q,
+                                                "note": "launches of %d submissions overlap: the sum of launches per step can exceed ms_per_step" % depth_q,
+                                                **by_kernel.get(kernel_of("spine"), {})}
+            filling = {k: v for k, v in by_kernel.items() if k != kernel_of("spine")}
+            if filling:
+                big = max(filling, key=lambda k: filling[k]["ms_per_step_sum_of_launches"])
+                roofline["largest_gpu_filling_kernel"] = {"kernel": big, **filling[big]}
         # the same figure for every stage (HIP-event brackets; on the low-priority streams they include the wait
         # for free compute resources, which rocprof's kernel begin / end timestamps do not)
         per_stage = {}
@@ -464,6 +529,7 @@ def main():
                          "ms_per_step_blocking_calls": None if sync_ms is None else round(sync_ms, 3),
                          "host_ms_per_submit": round(host_submit_s / steps * 1e3, 3),
                          "note": "the stages follow each other slice by slice on HIP streams of their own; launches overlap, so the sums exceed ms_per_step"},
+            "per_rank": per_rank,
             "parity": {"frames_byte_compared_with_oracle": checked, "streams_digest_checked_after_timed_steps": F,
                        "compressed_bytes_per_step_rank0": total_bytes,
                        "bits_per_pixel": round(total_bytes * 8 / (F * npix), 4)},

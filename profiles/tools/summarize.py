@@ -3,10 +3,11 @@
 traffic.json: per kernel, per step (64 S1 4K gray frames): FETCH_SIZE and WRITE_SIZE (KB counters x 1024), the
 correction MI355X_MICROARCH.md (HBM) prescribes, and the SQ instruction counters.
   * FETCH_SIZE reads exactly half the bytes of wide (16 B per lane) coalesced loads on gfx950.  Kernels whose reads are such
-    loads get fetch x 2 ("x2: uint4 loads"); kernels that read one dword or less per lane are exact ("x1"), which
-    round 1 confirmed on this workload (k_hist read the 530.8 MB of input once with dword loads and reported 0.53 GB; k_spine's
-    uint4 loads of 0.29 GB of events reported 0.146 GB).  k_pack_k mixes uint4 staging of the pixels with byte / dword reads
-    of the events: its figure is the raw counter plus the input size once more (the half the counter misses).
+    loads get fetch x 2 ("x2: uint4 loads").  k_hist and k_scatter read the input with unaligned 4- / 8-byte loads per lane,
+    several trips in flight (since round 3): the counter under-reports those too -- k_hist, whose only reads are the 530.8 MB of
+    input, reports ~ 334 MB.  Their rule is "calibrated": raw x (input bytes / k_hist's raw count), the factor taken from this very
+    run (k_hist reads every pixel exactly once, so it cannot have fetched less than the input).  k_pack_g reads its pixels with
+    16-byte loads per lane (counted at half) next to byte / word / dword reads of k, offsets and the run table: raw + the input size.
   * WRITE_SIZE is exact for full-line stores; partial-line stores (scatter) count the written sectors.
 """
 import collections
@@ -17,6 +18,7 @@ import os
 import sys
 
 out = sys.argv[1]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
@@ -47,21 +49,40 @@ for kind in ("fetch", "write", "sq", "sq2"):
                 counters[k][r["Counter_Name"]] += float(r["Counter_Value"]) / steps_in_command
 
 # which FETCH_SIZE rule applies to which kernel (see the module docstring)
-X2 = {"k_spine": "x2: uint4 loads of the event blocks", "k_pack_fused": "x2: uint4 staging of pixels and k",
+INPUT_BYTES = 64 * 3840 * 2160
+X2 = {"k_spine": "x2: uint4 loads of the event blocks",
       "k_pack": "x2: uint4 staging", "k_lengths": "x2: uint4 staging", "k_concat_planes": "x1",
-      "k_pack_k": "raw + input bytes: the uint4 staging of the pixels (once the input size) is its only wide load; events are read as bytes / dwords",
-      "k_pack_g": "raw + input bytes: the uint4 staging of the pixels (once the input size) is its only wide load; k, offsets and the run table are read as bytes / words / dwords",
-      "k_assign_serial": "x2: uint4 loads of the events and the block states"}
+      "k_pack_g": "raw + input bytes: the 16-byte loads of the pixels (twice the input size: the group and the row above it, counted at half) are its only wide loads; k, offsets and the run table are read as bytes / words / dwords",
+      "k_assign_serial": "x2: uint4 loads of the events and the block states",
+      "k_hist": "calibrated: raw x (input bytes / k_hist raw): the kernel reads the input exactly once",
+      "k_scatter": "calibrated: raw x (input bytes / k_hist raw): the same unaligned 4-byte loads as k_hist"}
 res = {}
 total = 0
 valu_total = 0
+valu_weighted_ns = 0.0
+hist_raw = counters.get("k_hist", {}).get("FETCH_SIZE", 0.0) * 1024
+calib = INPUT_BYTES / hist_raw if hist_raw else 1.0
+try:  # each kernel's share of 1.0 ns instructions, from the library this run used (profiles/tools/opcodes.py)
+    import opcodes
+    from felics_amd import build as fbuild_
+
+    shares = {}
+    for name, ctr in opcodes.histograms(fbuild_.ensure_lib()).items():
+        kshort = short(name)
+        if kshort and ("unsigned char" in name or "<" not in name):
+            shares[kshort] = opcodes.cheap_share(ctr)[1]
+except Exception as e:  # (no llvm-objdump on the path: the weighted figure is left out)
+    shares = None
+    print("opcode shares unavailable:", e)
 for k, c in sorted(counters.items()):
     fetch = c.get("FETCH_SIZE", 0.0) * 1024
     write = c.get("WRITE_SIZE", 0.0) * 1024
     rule = X2.get(k, "x1: dword-or-narrower loads per lane")
     fetch_c = fetch * (2 if rule.startswith("x2") else 1)
+    if rule.startswith("calibrated"):
+        fetch_c = fetch * calib
     if rule.startswith("raw + input bytes"):
-        fetch_c = fetch + 64 * 3840 * 2160  # the workload's input, read once with 16-byte loads and counted at half
+        fetch_c = fetch + INPUT_BYTES  # two spans of the input's size read with 16-byte loads, each counted at half
     e = {"fetch_bytes_raw": int(fetch), "fetch_rule": rule, "fetch_bytes_per_step": int(fetch_c), "write_bytes_per_step": int(write),
          "hbm_bytes_per_step": int(fetch_c + write)}
     for name in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_LDS",
@@ -72,11 +93,18 @@ for k, c in sorted(counters.items()):
     res[k] = e
     total += e["hbm_bytes_per_step"]
     valu_total += c.get("SQ_INSTS_VALU", 0.0)
+    if shares is not None and "SQ_INSTS_VALU" in c:
+        sh = shares.get(k, 0.0)
+        e["valu_share_1ns_class"] = round(sh, 3)
+        valu_weighted_ns += c["SQ_INSTS_VALU"] * (sh * 1.0 + (1.0 - sh) * 1.72)
 if counters:
     from felics_amd import build as fbuild
 
     res["_total_hbm_bytes_per_step"] = int(total)
     res["_valu_wave_insts_per_step"] = int(valu_total)
+    if shares is not None:
+        res["_valu_weighted_ns_per_step"] = int(valu_weighted_ns)  # SIMD-nanoseconds: / 1024 SIMDs = the step's additive issue time
+    res["_fetch_calibration_factor"] = round(calib, 4)
     res["_source_sha256"] = fbuild.source_hash()
     res["_workload"] = "64 synthetic S1 3840x2160 gray8 frames per step (bench.py default), blocking call"
     res["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (two groups) in four separate counter-only passes of `bench.py --steps 1 --warmup 0 "

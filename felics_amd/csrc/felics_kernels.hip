@@ -352,9 +352,10 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
         if (__ballot(ev && c >= 8u) != 0) {  // (a smooth frame's batches hold contexts 0 .. 7 only: three bits do)
             match_bit(3);
             match_bit(4);
-            if (__ballot(ev && c >= 32u) != 0) {  // contexts are < 512
+            if (__ballot(ev && c >= 32u) != 0) {  // contexts are < 256 (gray) / < 512 (Y, Co, Cg)
+                constexpr uint32_t CTX_BITS = nctx_of<T>() == 256 ? 8 : 9;
 #pragma unroll
-                for (uint32_t b = 5; b < 9; b++) match_bit(b);
+                for (uint32_t b = 5; b < CTX_BITS; b++) match_bit(b);
             }
         }
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));

@@ -391,11 +391,36 @@ def main():
         with ThreadPoolExecutor(max_workers=cores) as ex:
             list(ex.map(fapi2.decompress_bytes, sample))
         many = time.perf_counter() - t1
+        # a batch of thousands of streams (the 64, referenced 64 times over: every decoded image has a buffer of its own): the
+        # library switches to 64 streams per wave (lane = stream), whose rate per stream does not depend on the batch
+        big = None
+        try:
+            NB = 4096
+            o_big = np.array([offs0[i % F] for i in range(NB)], dtype=np.uint64)
+            l_big = np.array([lens0[i % F] for i in range(NB)], dtype=np.uint64)
+            d_big = torch.empty((NB, H, W), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _, stb = enc.decompress_batch_device(d_out.data_ptr(), o_big, l_big, d_big.data_ptr(), d_big.numel())
+            torch.cuda.synchronize()
+            big_s = time.perf_counter() - t1
+            if not (stb == 0).all() or not bool((d_big[NB - 1] == frames[(NB - 1) % F]).all()) or not bool((d_big[F + 1] == frames[1]).all()):
+                raise SystemExit("GPU decoder (64 streams per wave): pixels differ from the frames that were encoded")
+            del d_big
+            big = {"streams": NB, "gpu_MPix_s": round(NB * npix / big_s / 1e6, 1), "gpu_seconds_per_batch": round(big_s, 3),
+                   "MPix_s_per_stream": round(npix / big_s / 1e6, 3), "form": "64 streams per wave (lane = stream)"}
+        except torch.OutOfMemoryError:
+            big = None
         decode = {"gpu_MPix_s": round(F * npix / gpu_s / 1e6, 1), "gpu_seconds_per_batch": round(gpu_s, 3), "streams": F,
                   "gpu_note": "felics_decompress_batch_device: one wave per stream, %d streams = %d waves on 256 CUs" % (F, F),
+                  "large_batch": big,
                   "host_MPix_s_1_core": round(npix / one / 1e6, 1),
                   "host_MPix_s_%d_cores" % cores: round(len(sample) * npix / many / 1e6, 1),
                   "host_sample": "%d of the batch's streams, felics_decompress (C++)" % len(sample), "pixels_checked": True}
+        if big:  # a lane decodes at one rate whatever the batch: the batch from which the device beats this box's host cores
+            decode["break_even_streams"] = int(len(sample) * npix / many / 1e6 / big["MPix_s_per_stream"]) + 1
+            decode["break_even_note"] = ("streams per call from which 64 streams per wave beat %d host cores (host rate / rate per stream); "
+                                         "one wave per stream: ~540, saturating at ~2.3 GPix/s (profiles/r04/decode_scaling.txt)" % cores)
 
     if rank == 0:
         steps = max(args.steps, 1)

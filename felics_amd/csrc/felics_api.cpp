@@ -120,6 +120,7 @@ struct felics_ctx {
     int stage_launches[ST_COUNT] = {};
     DevBuf in, out;  // staging of the host-pointer entry points
     DevBuf dec_meta, dec_planes;  // GPU decoder: offsets | lens | status of a batch; Y / Co / Cg planes of RGB streams
+    DevBuf dec_lane_table;        // gray streams decoded 64 to a wave: the estimator rows that do not fit in LDS (3 KB per stream, zeroed per call)
     DevBuf dec_table;             // 16-bit streams: estimator tables in HBM (8.4 MB per stream of a pass), zeroed once, rows tagged with an epoch
     uint32_t dec_epoch = 0;       // last epoch handed out (three per call: one per plane)
 };
@@ -905,6 +906,7 @@ void felics_ctx_destroy(felics_ctx *ctx) {
     release(ctx->dec_meta);
     release(ctx->dec_planes);
     release(ctx->dec_table);
+    release(ctx->dec_lane_table);
     delete ctx;
 }
 
@@ -1201,8 +1203,20 @@ int felics_decompress_batch_device(felics_ctx *ctx, size_t n, const void *d_stre
     HIP_TRY(ctx, hipMemcpyAsync(d_off, offsets, n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_len, lens, n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(d_status, 0xFF, n * 4, s));
-    HIP_TRY(ctx, launch_decode8(s, (const uint8_t *)d_streams, d_off, d_len, (uint32_t)n, hdr.width, hdr.height, hdr.color_type,
-                                (uint8_t *)d_pixels, d_planes, d_status));
+    // hundreds of gray streams and more: 64 streams per wave (lane = stream); fewer, or RGB: one wave per stream
+    // (FELICS_TEST_DECODE_LANES=1 / =0 force one form whatever the batch: tests)
+    bool by_lane = planes == 1 && hdr.width >= 8 && n >= DECODE8_LANES_MIN_STREAMS;
+    if (const char *e = getenv("FELICS_TEST_DECODE_LANES")) by_lane = planes == 1 && hdr.width >= 8 && atoi(e) != 0;
+    if (by_lane) {
+        const size_t tb = decode8_lanes_table_bytes((uint32_t)n);
+        if ((rc = reserve(ctx, ctx->dec_lane_table, tb)) != 0) return fail_all(rc);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dec_lane_table.p, 0, tb, s));
+        HIP_TRY(ctx, launch_decode8_lanes(s, (const uint8_t *)d_streams, d_off, d_len, (uint32_t)n, hdr.width, hdr.height, (uint8_t *)d_pixels,
+                                          (uint32_t *)ctx->dec_lane_table.p, d_status));
+    } else {
+        HIP_TRY(ctx, launch_decode8(s, (const uint8_t *)d_streams, d_off, d_len, (uint32_t)n, hdr.width, hdr.height, hdr.color_type,
+                                    (uint8_t *)d_pixels, d_planes, d_status));
+    }
     HIP_TRY(ctx, hipMemcpyAsync(status, d_status, n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     for (size_t i = 0; i < n; i++)

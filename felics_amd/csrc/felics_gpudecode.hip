@@ -285,6 +285,272 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
     if (lane == 0) status[img] = rc;
 }
 
+// ------------------------------------------------------------------------------------------
+// Sixty-four streams per wave, LANE = stream (8-bit gray, batches of hundreds of streams and more).
+//
+// The streams of a call have one shape, so all of them are at the same pixel at the same time: the walk over (x, y) and the
+// neighbour rule's case analysis are wave-uniform, and only what depends on a stream's content differs between the lanes --
+// the bit reader (a 64-bit window, the position and one prefetched dword per lane), the two neighbours, the estimator row.
+// Per pixel every lane executes both kinds of code under its own flag; a wave decodes 64 pixels in about the time
+// k_decode8 decodes one, at the price of memory operations that are gathers (64 addresses per instruction):
+//   * the stream: one dword per lane every ~8 pixels, asked for a whole dword ahead;
+//   * the row above: read back from the stream's own OUTPUT image, four samples per lane at a time (a CU sees its own
+//     stores; 64 rows do not fit in LDS: 3840 x 64 bytes);
+//   * the estimator table: 256 contexts x six 16-bit counters = 3 KB per stream (a counter of an 8-bit gray plane stays
+//     below 2^16: the smallest grows by >= 6 per event, the largest by <= 255, so a halving period adds at most 44 000 on
+//     top of the halved rest).  The first DEC8L_HOT contexts of every stream live in LDS, one dword per lane and pair of
+//     counters (lane-interleaved: no bank conflict whatever the contexts), the others in a zeroed table in HBM: smooth and
+//     natural content keeps to the LDS rows, noise pays an L2 round trip per event.
+// Error behaviour as in k_decode8: every read of a stream is bounded by its length, a lane that has failed keeps walking
+// (on zeros, its samples clamped into range so that contexts stay inside the table) and reports its first error.
+// Needs W >= 8 (the read-back of the row above looks four samples ahead of a row's end).
+// ------------------------------------------------------------------------------------------
+
+constexpr uint32_t DEC8L_HOT = 32;                 // contexts per stream in LDS: 64 x 32 x 12 B = 24 KB per wave
+constexpr uint32_t DEC8L_TABLE_DW = 256 * 3;       // dwords per stream in HBM: 256 contexts x three pairs of u16 counters
+
+namespace {
+
+// MSB-first bit reader of ONE LANE over [base, base + len) (bitstream-io BitReader<_, BigEndian>)
+struct LaneReader {
+    const uint32_t *al;   // aligned-down dword pointer of the stream's first byte
+    uint32_t total_dw;    // dwords from `al` that hold stream bytes
+    uint32_t pos;         // dwords moved into acc so far
+    uint32_t nxt;         // dword `pos` as it lies in memory (zero past the end): asked for when dword pos - 1 was taken and first
+                          // LOOKED AT when it is taken itself (the byte swap at the load would be a wait for the load)
+    uint64_t acc;         // unread bits, left-aligned
+    uint32_t navail;      // valid bits in acc
+    uint64_t end_bit;     // bits from `al` to the end of the stream
+
+    __device__ __forceinline__ uint32_t fetch(uint32_t i) const { return i < total_dw ? al[i] : 0u; }
+    __device__ __forceinline__ void init(const uint8_t *p, uint64_t n) {
+        const uint32_t skew = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u);
+        al = reinterpret_cast<const uint32_t *>(p - skew);
+        total_dw = (uint32_t)std::min<uint64_t>((skew + n + 3u) >> 2, 0xFFFFFFFFull);
+        pos = 0;
+        nxt = fetch(0);
+        acc = 0;
+        navail = 0;
+        end_bit = (skew + n) * 8u;
+        refill();
+        if (skew) {  // the first dword starts before the stream: drop those bytes
+            acc <<= 8u * skew;
+            navail -= 8u * skew;
+        }
+    }
+    // at least 33 valid bits in acc afterwards (zeros past the end of the stream)
+    __device__ __forceinline__ void refill() {
+        if (navail <= 32u) {
+            acc |= (uint64_t)__builtin_bswap32(nxt) << (32u - navail);
+            navail += 32u;
+            pos++;
+            nxt = fetch(pos);
+        }
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t n) {  // the next n <= 32 bits; the caller has refilled (n <= navail)
+        const uint32_t v = n ? (uint32_t)(acc >> (64u - n)) : 0u;
+        acc <<= n;
+        navail -= n;
+        return v;
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t n) {
+        refill();
+        return take(n);
+    }
+    __device__ __forceinline__ bool failed() const { return (uint64_t)pos * 32u - navail > end_bit; }
+    __device__ __forceinline__ uint64_t unary0() {  // ones before the first zero, the zero consumed (read_unary0)
+        uint64_t q = 0;
+        while (true) {
+            refill();
+            const uint32_t top = (uint32_t)(acc >> 32);
+            const uint32_t ones = top == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_clz(~top);
+            if (ones == 32u) {
+                q += 32u;
+                take(32u);
+                if (failed()) return q;
+                continue;
+            }
+            take(ones + 1u);
+            return q + ones;
+        }
+    }
+};
+
+// four samples of a stream's own output image (unaligned dword; the image is this wave's to write and to read)
+__device__ __forceinline__ uint32_t read_back4(const uint8_t *p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void k_decode8_lanes(const uint8_t *__restrict__ streams, const uint64_t *__restrict__ offsets,
+                                                      const uint64_t *__restrict__ lens, uint32_t n, uint32_t W, uint32_t H,
+                                                      uint8_t *pixels, uint32_t *table, int *__restrict__ status) {
+    __shared__ uint32_t hot[DEC8L_HOT * 3 * 64];  // [context][pair of counters][lane]
+    const uint32_t lane = lane_id();
+    const uint32_t img = blockIdx.x * 64 + lane;
+    for (uint32_t i = lane; i < DEC8L_HOT * 3 * 64; i += 64) hot[i] = 0;  // KEstimator::new (the HBM rows arrive zeroed)
+    __builtin_amdgcn_wave_barrier();
+    if (img >= n) return;
+    const uint8_t *s = streams + offsets[img];
+    const uint64_t slen = lens[img];
+    const uint64_t npix = (uint64_t)W * H;
+    // header (format.rs:63-84) must be the one the caller announced
+    int rc = FELICS_OK;
+    if (slen < FELICS_HEADER_BYTES) {
+        rc = FELICS_E_IO;
+    } else {
+        const uint32_t w = ((uint32_t)s[6] << 24) | ((uint32_t)s[7] << 16) | ((uint32_t)s[8] << 8) | s[9];
+        const uint32_t h = ((uint32_t)s[10] << 24) | ((uint32_t)s[11] << 16) | ((uint32_t)s[12] << 8) | s[13];
+        if (s[0] != 'F' || s[1] != 'L' || s[2] != 'C' || s[3] != 'S') rc = FELICS_E_INVALID_SIGNATURE;
+        else if (s[4] > 1) rc = FELICS_E_INVALID_COLOR_TYPE;
+        else if (s[5] > 1) rc = FELICS_E_INVALID_PIXEL_DEPTH;
+        else if (s[4] != 0 || s[5] != 0 || w != W || h != H) rc = FELICS_E_INVALID_DIMENSIONS;
+    }
+    if (rc != FELICS_OK) {  // nothing of this stream is decoded (its lane leaves; the others go on)
+        status[img] = rc;
+        return;
+    }
+    LaneReader br;
+    br.init(s + FELICS_HEADER_BYTES, slen - FELICS_HEADER_BYTES);
+    const int32_t p0 = (int32_t)br.get(32), p1 = (int32_t)br.get(32);  // compression.rs:166-167
+    if (br.failed()) rc = FELICS_E_IO;
+    if (npix == 0 || rc != FELICS_OK) {
+        status[img] = rc;
+        return;
+    }
+    uint32_t *tab = table + (uint64_t)img * DEC8L_TABLE_DW;
+    uint8_t *out = pixels + (uint64_t)img * npix;
+    uint32_t *myhot = hot + lane;
+    // (x, y) and everything derived from them alone is wave-uniform: every stream has the same shape
+    int left = 0, left2 = 0;
+    uint32_t up4 = 0, up4_next = 0, out4 = 0;
+    uint32_t out_of_range = 0;  // OR of every sample as decoded: above 255 if one did not fit eight bits (negative ones included)
+    int first_col2 = 0;
+    for (uint32_t y = 0; y < H; y++) {
+      uint8_t *row = out + (uint64_t)y * W;  // this row of the stream's image, and the one above it
+      const uint8_t *prow = row - W;
+      if (y > 0) {
+          up4 = read_back4(prow);                   // row above, samples 0 .. 3 (later groups are asked for four samples ahead)
+          if (4 < W) up4_next = read_back4(prow + 4);
+          // second neighbour of a row's first pixel (misc.rs:14-23): two rows up, or above-right in row 1
+          first_col2 = y >= 2 ? (int)prow[-(int64_t)W] : (W > 1 ? (int)((up4 >> 8) & 0xFFu) : 0);
+      }
+      for (uint32_t x = 0; x < W; x++) {
+        const uint32_t xs = x & 3u;
+        if (xs == 0 && y > 0 && x != 0) {
+            up4 = up4_next;
+            if (x + 4 < W) up4_next = read_back4(prow + x + 4);
+        }
+        int pv;
+        if (y == 0 && x < 2) {
+            pv = x == 0 ? p0 : p1;
+        } else {
+            const int above = (int)((up4 >> (8u * xs)) & 0xFFu);
+            const bool row0 = y == 0, col0 = x == 0 && !row0;
+            const int v1 = col0 ? above : left;
+            const int v2 = col0 ? first_col2 : (row0 ? left2 : above);
+            const int hi = max(v1, v2), lo = min(v1, v2);
+            const uint32_t ctx = (uint32_t)(hi - lo);  // <= 255: every sample kept is in range
+            // The context's row for every lane, whether its pixel turns out to be an event or not (no divergence, and the LDS
+            // round trip runs beside the arithmetic below): three pairs of 16-bit counters; hot contexts from LDS.
+            const bool is_hot = ctx < DEC8L_HOT;
+            const uint32_t hrow = min(ctx, DEC8L_HOT - 1u) * 3u * 64u;
+            uint32_t w01 = myhot[hrow], w23 = myhot[hrow + 64], w45 = myhot[hrow + 128];
+            br.refill();  // >= 33 valid bits: both kinds of code are read off the top 32 of them, then consumed in one go
+            const uint32_t top = (uint32_t)(br.acc >> 32);
+            const bool in_range = (top >> 31) != 0;
+            // -- in range: `1`, then the phased-in code of p - L in m or m + 1 bits (phase_in_coding.rs:86-112), m <= 7
+            const uint32_t nn = ctx + 1;
+            const uint32_t m = 31u - (uint32_t)__builtin_clz(nn);
+            const uint32_t right_p = (2u << m) - nn, left_p = nn - (1u << m);
+            const uint32_t t1 = top << 1;
+            uint32_t r = (t1 >> 1) >> (31u - m);               // the m bits behind the flag
+            const uint32_t extra = (t1 >> (31u - m)) & 1u;      // the bit behind them
+            const uint32_t longer = r >= right_p ? 1u : 0u;     // the code has one more bit
+            r = longer ? (r - right_p) * 2u + right_p + extra : r;
+            uint32_t rot = r + left_p;                          // rotate_left: (r + left_p) mod n, r < n
+            rot = rot >= nn ? rot - nn : rot;
+            const int pv_in = lo + (int)rot;
+            const uint32_t bits_in = 1u + m + longer;
+            // -- out of range: `0`, above / below flag, q ones, `0`, k bits -- off the same 32 bits when it fits in them
+            const bool above_flag = ((top >> 30) & 1u) != 0;
+            if (!in_range && !is_hot) {  // (noise: a cold context's row comes from the stream's table in HBM)
+                w01 = tab[ctx * 3 + 0];
+                w23 = tab[ctx * 3 + 1];
+                w45 = tab[ctx * 3 + 2];
+            }
+            uint32_t S[6] = {w01 & 0xFFFFu, w01 >> 16, w23 & 0xFFFFu, w23 >> 16, w45 & 0xFFFFu, w45 >> 16};
+            // get_k: smallest counter, ties to the largest k (parameter_selection.rs:71-85)
+            const uint32_t key = min(min(min((S[0] << 3) | 7u, (S[1] << 3) | 6u), min((S[2] << 3) | 5u, (S[3] << 3) | 4u)),
+                                     min((S[4] << 3) | 3u, (S[5] << 3) | 2u));
+            const uint32_t k = 7u - (key & 7u);
+            const uint32_t t2 = top << 2;                                  // 30 bits of the stream, two zeros behind them
+            const uint32_t ones = (uint32_t)__builtin_clz(~t2);            // (<= 30: ~t2 ends in ones)
+            const bool fits = ones + 1u + k <= 30u;                        // unary part, its zero and the k bits lie inside the 30
+            uint32_t e = (ones << k) + (((t2 << (ones & 31u)) << 1 >> 1) >> (31u - k));  // k bits behind the zero (k <= 5)
+            uint32_t nbits = in_range ? bits_in : 3u + ones + k;
+            if (!in_range && !fits) {
+                // a long code (or the end of the stream): the general reader, bit field by bit field
+                br.take(2);
+                const uint64_t q = br.unary0();
+                const uint64_t e64 = (q << k) + br.get(k);
+                e = (uint32_t)e64;
+                if (e64 > 1024u) {  // no sample of an 8-bit plane is that far from its neighbours
+                    if (rc == FELICS_OK) rc = e64 > 0xFFFFFFFFull ? FELICS_E_VALUE_OVERFLOW : FELICS_E_INVALID_VALUE;
+                    e = 0;
+                }
+                nbits = 0;
+            }
+            br.acc <<= nbits;  // (nbits <= 32 < the valid bits)
+            br.navail -= nbits;
+            if (!in_range) {
+                // update (parameter_selection.rs:49-68): add the six Rice lengths, halve when the smallest passes 1024
+                uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+                for (uint32_t kk = 0; kk < 6; kk++) {
+                    S[kk] += (e >> kk) + 1u + kk;
+                    mn = min(mn, S[kk]);
+                }
+                const uint32_t hsh = mn > 1024u ? 1u : 0u;
+                w01 = (S[0] >> hsh) | ((S[1] >> hsh) << 16);
+                w23 = (S[2] >> hsh) | ((S[3] >> hsh) << 16);
+                w45 = (S[4] >> hsh) | ((S[5] >> hsh) << 16);
+                if (is_hot) {
+                    myhot[hrow] = w01;
+                    myhot[hrow + 64] = w23;
+                    myhot[hrow + 128] = w45;
+                } else {
+                    tab[ctx * 3 + 0] = w01;
+                    tab[ctx * 3 + 1] = w23;
+                    tab[ctx * 3 + 2] = w45;
+                }
+            }
+            pv = in_range ? pv_in : (above_flag ? hi + (int)e + 1 : lo - (int)e - 1);
+        }
+        // try_into::<u8>() would fail on anything outside 0 .. 255: remembered (two instructions per pixel instead of eight) and
+        // reported at the end of the row; the sample is cut to eight bits so that a failed stream's contexts stay inside the table
+        out_of_range |= (uint32_t)pv;
+        pv &= 255;
+        out4 |= (uint32_t)pv << (8u * xs);
+        left2 = left;
+        left = pv;
+        if (xs == 3u) {  // four samples complete: one (unaligned) dword to the stream's image
+            __builtin_memcpy(row + (x - 3u), &out4, 4);
+            out4 = 0;
+        } else if (x + 1 == W) {  // the last one to three samples of a row
+            for (uint32_t j = 0; j <= xs; j++) row[(x - xs) + j] = (uint8_t)(out4 >> (8u * j));
+            out4 = 0;
+        }
+      }
+      if (rc == FELICS_OK) rc = br.failed() ? FELICS_E_IO : (out_of_range > 255u ? FELICS_E_INVALID_VALUE : FELICS_OK);
+    }
+    if (br.failed() && rc == FELICS_OK) rc = FELICS_E_IO;  // (whatever else: it was decoding padding)
+    status[img] = rc;
+}
+
 // ycocg_to_rgb (color_transform.rs:20-26) on the decoded planes, range-checked like try_into::<u8>()
 __global__ __launch_bounds__(256) void k_ycocg8_to_rgb(const int16_t *__restrict__ planes, uint8_t *__restrict__ pixels,
                                                        uint32_t npix, int *__restrict__ status) {
@@ -526,6 +792,16 @@ hipError_t launch_decode16(hipStream_t s, const uint8_t *streams, const uint64_t
         const uint32_t bx = (uint32_t)std::min<uint64_t>((npix + 255) / 256, 1024u);
         if (bx) hipLaunchKernelGGL(k_ycocg16_to_rgb, dim3(bx, n), dim3(256), 0, s, planes, pixels, (uint32_t)npix, status);
     }
+    return hipGetLastError();
+}
+
+size_t decode8_lanes_table_bytes(uint32_t n) { return (size_t)n * DEC8L_TABLE_DW * 4; }
+
+// lane = stream (gray8, W >= 8); `table` = decode8_lanes_table_bytes(n) bytes, all zero
+hipError_t launch_decode8_lanes(hipStream_t s, const uint8_t *streams, const uint64_t *offsets, const uint64_t *lens, uint32_t n,
+                                uint32_t W, uint32_t H, uint8_t *pixels, uint32_t *table, int *status) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_decode8_lanes, dim3((n + 63) / 64), dim3(64), 0, s, streams, offsets, lens, n, W, H, pixels, table, status);
     return hipGetLastError();
 }
 

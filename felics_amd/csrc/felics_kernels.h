@@ -201,6 +201,13 @@ size_t decode16_table_bytes(uint32_t n);
 hipError_t launch_decode16(hipStream_t s, const uint8_t *streams, const uint64_t *offsets, const uint64_t *lens, uint32_t n,
                            uint32_t W, uint32_t H, uint32_t color, uint16_t *pixels, int32_t *planes, uint32_t *table,
                            uint32_t epoch0, int *status);
+// The same for large batches of gray streams (felics_gpudecode.hip, k_decode8_lanes): 64 streams per wave, lane = stream; needs W >= 8
+// and a zeroed table of decode8_lanes_table_bytes(n) bytes (3 KB per stream: the estimator rows that do not live in LDS).
+constexpr uint32_t DECODE8_LANES_MIN_STREAMS = 1536;  // measured (profiles/r04/decode_scaling.txt): one wave per stream saturates at ~2.3 GPix/s from ~1000
+                                                       // streams, a lane decodes 1.47 MPix/s whatever the batch: the forms cross at ~1500 streams
+size_t decode8_lanes_table_bytes(uint32_t n);
+hipError_t launch_decode8_lanes(hipStream_t s, const uint8_t *streams, const uint64_t *offsets, const uint64_t *lens, uint32_t n,
+                                uint32_t W, uint32_t H, uint8_t *pixels, uint32_t *table, int *status);
 hipError_t launch_decode8(hipStream_t s, const uint8_t *streams, const uint64_t *offsets, const uint64_t *lens, uint32_t n,
                           uint32_t W, uint32_t H, uint32_t color, uint8_t *pixels, int16_t *planes, int *status);
 

@@ -242,3 +242,148 @@ def test_sixteen_bit_streams_on_the_device(enc, oracle):
             assert status[i] != 0, i
         elif status[i] == 0:
             assert (host[i * img.size:(i + 1) * img.size].reshape(img.shape) == want).all(), i
+
+
+def _forced(value):
+    """context manager: FELICS_TEST_DECODE_LANES for the calls inside (read per call by the library)"""
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        os.environ["FELICS_TEST_DECODE_LANES"] = value
+        try:
+            yield
+        finally:
+            del os.environ["FELICS_TEST_DECODE_LANES"]
+    return cm()
+
+
+def test_lane_decoder_shapes_and_content(enc, oracle):
+    """k_decode8_lanes (64 gray streams per wave, lane = stream), forced on small batches: the reference's shapes with W >= 8,
+    odd widths (the read-back of the row above is four samples wide, rows end anywhere), extreme content (flat, checker,
+    ramps, spikes: codes of hundreds of bits), noise (every context, the estimator rows in HBM) -- against the original
+    pixels and the host decoder's."""
+    from felics_amd import synth
+
+    rng = np.random.default_rng(21)
+    with _forced("1"):
+        for w, h in [(8, 1), (9, 3), (10, 7), (11, 2), (63, 5), (64, 4), (65, 9), (100, 40), (124, 274), (1447, 8), (680, 480)]:
+            imgs = [rng.integers(0, 256, size=(h, w)).astype(np.uint8) for _ in range(3)]
+            imgs.append((np.add.outer(np.arange(h), np.arange(w)) // 2 % 256).astype(np.uint8))
+            imgs.append(np.full((h, w), 200, np.uint8))
+            imgs.append(((np.add.outer(np.arange(h), np.arange(w)) & 1) * 255).astype(np.uint8))
+            spikes = rng.integers(100, 104, size=(h, w)).astype(np.uint8)
+            spikes[rng.random((h, w)) < 0.02] = 255
+            spikes[rng.random((h, w)) < 0.02] = 0
+            imgs.append(spikes)
+            imgs.append(synth.gray8(w, h, 3, "S1"))
+            streams = [oracle.compress(im) for im in imgs]
+            hdr, back = _decode_batch(enc, streams, (h, w), np.uint8)
+            assert (hdr.width, hdr.height) == (w, h)
+            for b, im, s in zip(back, imgs, streams):
+                assert (b == im).all(), (w, h)
+                assert (b == oracle.decompress(s)).all()
+        # more streams than one wave holds, a ragged last wave
+        imgs = [synth.gray8(96, 33, f, "S2" if f % 3 == 0 else "S1") for f in range(130)]
+        _, back = _decode_batch(enc, [oracle.compress(im) for im in imgs], (33, 96), np.uint8)
+        assert all((b == im).all() for b, im in zip(back, imgs))
+
+
+def test_lane_decoder_corrupt_streams(enc, oracle):
+    """The corrupt-stream list of test_corrupt_streams_give_error_codes through the lane decoder: every stream gets a status,
+    the good ones beside the bad ones in the same wave decode intact, nothing faults."""
+    import felics_amd
+    import torch
+
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, size=(60, 70), dtype=np.uint8)
+    good = oracle.compress(img)
+    other = oracle.compress(rng.integers(0, 256, size=(61, 70), dtype=np.uint8))
+    bad = [good[: len(good) // 2], good[:20], b"XLCS" + good[4:], good[:4] + b"\x07" + good[5:], good[:5] + b"\x09" + good[6:], other,
+           good[:30] + b"\xff" * (len(good) - 30), good[:30] + bytes(len(good) - 30)]
+    for _ in range(40):
+        b = bytearray(good)
+        b[int(rng.integers(14, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        bad.append(bytes(b))
+    streams = [good] + bad + [good]
+    offs, blob = [], bytearray()
+    for s in streams:
+        offs.append(len(blob))
+        blob += s + bytes((-len(s)) % 16)
+    d_in = torch.from_numpy(np.frombuffer(bytes(blob) + bytes(16), dtype=np.uint8).copy()).cuda()
+    d_px = torch.zeros(img.size * len(streams), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with _forced("1"), pytest.raises(felics_amd.DecompressionError) as ei:
+        enc.decompress_batch_device(d_in.data_ptr(), offs, [len(s) for s in streams], d_px.data_ptr(), d_px.numel())
+    status = ei.value.status
+    assert status[0] == 0 and status[-1] == 0
+    host = d_px.cpu().numpy()
+    assert (host[: img.size].reshape(img.shape) == img).all() and (host[-img.size:].reshape(img.shape) == img).all()
+    assert status[1] == -1 and status[2] == -1          # truncated: IoError
+    assert status[3] == -7 and status[4] == -5 and status[5] == -6 and status[6] == -4
+    for i, s in enumerate(streams[1:-1], start=1):
+        try:
+            want = oracle.decompress(s)
+            host_ok = want.shape == img.shape
+        except Exception:
+            host_ok = False
+        if not host_ok:
+            assert status[i] != 0, i
+        elif status[i] == 0:
+            assert (host[i * img.size:(i + 1) * img.size].reshape(img.shape) == want).all(), i
+
+
+def test_three_hundred_mixed_streams(enc, oracle):
+    """Both forms of the device decoder (one wave per stream; 64 streams per wave, which the library picks from 1536 gray streams
+    up) on 300 streams of one shape and mixed content -- synthetic S1 / S2 / S3 frames, ramps with spikes, crops of the golden natural images -- encoded on the
+    GPU, decoded back on the GPU and compared with the frames; some of the streams also through the oracle's decoder."""
+    import torch
+    from felics_amd import synth
+
+    w, h = 200, 96
+    rng = np.random.default_rng(33)
+    nat = []
+    from PIL import Image
+
+    for path in sorted(glob.glob(os.path.join(GOLDEN, "*.tif*"))):
+        if path.endswith(".felics"):
+            continue
+        im = np.array(Image.open(path))
+        if im.dtype == np.uint8 and im.ndim == 2 and im.shape[0] >= h and im.shape[1] >= w:
+            nat.append(im)
+    assert nat
+    frames = []
+    for f in range(300):
+        kind = f % 5
+        if kind == 0:
+            frames.append(synth.gray8(w, h, f, "S1"))
+        elif kind == 1:
+            frames.append(synth.gray8(w, h, f, "S2"))
+        elif kind == 2:
+            frames.append(synth.gray8(w, h, f, "S3") if f % 2 else (np.add.outer(np.arange(h), np.arange(w)) * (f % 7 + 1) // 3 % 256).astype(np.uint8))
+        elif kind == 3 and nat:
+            im = nat[f % len(nat)]
+            y0, x0 = int(rng.integers(0, im.shape[0] - h + 1)), int(rng.integers(0, im.shape[1] - w + 1))
+            frames.append(np.ascontiguousarray(im[y0:y0 + h, x0:x0 + w]))
+        else:
+            sp = rng.integers(60, 64, size=(h, w)).astype(np.uint8)
+            sp[rng.random((h, w)) < 0.01] = 255
+            frames.append(sp)
+    d_in = torch.from_numpy(np.stack(frames)).cuda()
+    cap = len(frames) * (w * h * 2 + 64)
+    d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    offs, lens = enc.compress_batch_device(d_in.data_ptr(), len(frames), w, h, 0, 0, d_out.data_ptr(), cap)
+    for form in ("0", "1"):
+        d_px = torch.zeros_like(d_in)
+        with _forced(form):
+            hdr, status = enc.decompress_batch_device(d_out.data_ptr(), offs, lens, d_px.data_ptr(), d_px.numel())
+        assert (status == 0).all() and (hdr.width, hdr.height) == (w, h)
+        assert bool((d_px == d_in).all()), form
+    # the library's own choice for a batch of thousands of streams (the 300, referenced seven times over)
+    offs7, lens7 = np.tile(np.asarray(offs, dtype=np.uint64), 7), np.tile(np.asarray(lens, dtype=np.uint64), 7)
+    d_px7 = torch.zeros((7,) + tuple(d_in.shape), dtype=torch.uint8, device="cuda")
+    hdr, status = enc.decompress_batch_device(d_out.data_ptr(), offs7, lens7, d_px7.data_ptr(), d_px7.numel())
+    assert (status == 0).all() and all(bool((d_px7[r] == d_in).all()) for r in range(7))
+    host = d_out.cpu().numpy()
+    for i in (0, 1, 63, 64, 255, 299):
+        assert (oracle.decompress(host[int(offs[i]): int(offs[i] + lens[i])].tobytes()) == frames[i]).all(), i

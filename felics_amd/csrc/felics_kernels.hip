@@ -294,8 +294,8 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
                                                  ET *__restrict__ sorted_e, uint32_t *__restrict__ pix_of,
                                                  uint32_t W, uint32_t npix, uint32_t ntiles, uint32_t tile_begin,
                                                  uint32_t tile_end, uint32_t nplanes) {
-    constexpr uint32_t RING = 512;  // a trip adds at most 256 events to fewer than 64 left over
-    static_assert(RING >= 256 + 64 && (RING & (RING - 1)) == 0, "the ring holds a trip's events behind a partial batch, and is indexed with a mask");
+    constexpr uint32_t RING = 1024;  // a round of two trips adds at most 512 events to fewer than 64 left over
+    static_assert((RING & (RING - 1)) == 0, "the ring is indexed with a mask");
     static_assert(SORT_TILE <= (1u << 13), "ring records keep the pixel's offset in its tile in 13 bits");
     __shared__ uint32_t runs[4][nctx_of<T>()];
     __shared__ uint32_t rings[4][RING];
@@ -375,11 +375,18 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
                 pix_of[dest] = plane_first + begin + off;
         }
     };
-    // The loads of the next AHEAD trips are in flight while a trip is compacted, ranked and stored (see k_hist).
-    constexpr uint32_t AHEAD = 3;
+    // Trips go in ROUNDS of PAIR: a round's loads are issued together at the top of the round before it, its events are
+    // compacted into the ring trip by trip and ranked / stored at its end.  The stores make the compiler wait for EVERYTHING
+    // a wave has in flight wherever it uses a loaded value (gfx9 counts loads and stores in one in-order counter and the
+    // number of batches stored is data-dependent), so a load is waited for one "wait interval" after it was issued whatever
+    // the depth of the prefetch: with one trip per interval (round 3: three trips of prefetch, one trip per wait) that was
+    // less than a memory round trip under load, and every trip stood for the rest of it; a round of two trips is longer
+    // than the round trip.
+    constexpr uint32_t PAIR = 2;
+    static_assert(RING >= PAIR * 256 + 64, "the ring holds a round's events behind a partial batch");
     auto is_interior = [&](uint32_t r, uint32_t x, uint32_t y) { return y > 0 && x + 256 <= W && r + 256 <= end; };  // (a span from the first column included)
-    Interior4<T> pre[AHEAD];
-    bool have[AHEAD];
+    Interior4<T> pre[PAIR];
+    bool have[PAIR];
     uint32_t ri = begin, yi = begin / W, xi = begin - yi * W;  // the next trip to issue
     auto issue = [&](Interior4<T> &slot, bool &h) {
         h = ri < end && is_interior(ri, xi, yi);
@@ -392,71 +399,79 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
             xi -= q * W;
         }
     };
+    // The events of a trip are compacted into a per-wave ring in LDS, raster order kept, and ranked / stored 64 at a time:
+    // every ballot and every store then works on 64 events instead of the ~35 % of a row's lanes that hold one.
+    auto trip = [&](const Interior4<T> &now, bool interior, uint32_t row0) {
+        if (interior) {
+            // lane l takes pixels row0 + 4l .. + 3 (two wide loads instead of twelve byte loads); a prefix
+            // sum of the lanes' event counts keeps the ring in raster order
+            const uint32_t off0 = row0 - begin + 4 * lane;
+            PixelClass pc[4];
+            classify_loaded4(now, pc);
+            uint32_t nev = 0;
 #pragma unroll
-    for (uint32_t d = 0; d < AHEAD; d++) issue(pre[d], have[d]);
-    for (uint32_t row0 = begin; row0 < end;) {
+            for (uint32_t j = 0; j < 4; j++) nev += pc[j].cls != CLS_IN ? 1u : 0u;
+            const uint32_t incl = wave_incl_scan(nev);
+            uint32_t pos = qtail + incl - nev;
 #pragma unroll
-        for (uint32_t d = 0; d < AHEAD; d++) {
-            if (row0 < end) {
-                const bool interior = have[d];
-                const Interior4<T> now = pre[d];
-                issue(pre[d], have[d]);
-                // The events of the trip are compacted into a per-wave ring in LDS, raster order kept, and ranked /
-                // stored 64 at a time: every ballot and every store then works on 64 events instead of the ~35 %
-                // of a row's lanes that hold one.
-                if (interior) {
-                    // lane l takes pixels row0 + 4l .. + 3 (two wide loads instead of twelve byte loads); a prefix
-                    // sum of the lanes' event counts keeps the ring in raster order
-                    const uint32_t off0 = row0 - begin + 4 * lane;
-                    PixelClass pc[4];
-                    classify_loaded4(now, pc);
-                    uint32_t nev = 0;
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; j++) nev += pc[j].cls != CLS_IN ? 1u : 0u;
-                    const uint32_t incl = wave_incl_scan(nev);
-                    uint32_t pos = qtail + incl - nev;
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; j++) {
-                        if (pc[j].cls != CLS_IN) {
-                            ring[pos & (RING - 1u)] = (pc[j].ctx << 22) | (pc[j].val << 13) | (off0 + j);
-                            pos++;
-                        }
-                    }
-                    qtail += readlane(incl, 63);
-                } else {
-                    bool evs[4];
-                    uint32_t cs[4], es[4];
-                    Coord xy;
-                    xy.set(row0 + lane, W);
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) {
-                        const uint32_t i = row0 + u * 64 + lane;
-                        evs[u] = false;
-                        cs[u] = 0;
-                        es[u] = 0;
-                        if (i < end && i >= 2) {
-                            const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
-                            evs[u] = pc.cls != CLS_IN;
-                            cs[u] = pc.ctx;
-                            es[u] = pc.val;
-                        }
-                        xy.advance(64, W);
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) {  // row by row, lane by lane
-                        const uint64_t m = __ballot(evs[u]);
-                        if (m == 0) continue;
-                        if (evs[u]) ring[(qtail + mbcnt(m)) & (RING - 1u)] = (cs[u] << 22) | (es[u] << 13) | (row0 - begin + u * 64 + lane);
-                        qtail += (uint32_t)__popcll(m);
-                    }
-                }
-                row0 += 256;
-                __builtin_amdgcn_wave_barrier();
-                while (qtail - qhead >= 64u) {
-                    drain(64u);
-                    qhead += 64u;
+            for (uint32_t j = 0; j < 4; j++) {
+                if (pc[j].cls != CLS_IN) {
+                    ring[pos & (RING - 1u)] = (pc[j].ctx << 22) | (pc[j].val << 13) | (off0 + j);
+                    pos++;
                 }
             }
+            qtail += readlane(incl, 63);
+        } else {
+            bool evs[4];
+            uint32_t cs[4], es[4];
+            Coord xy;
+            xy.set(row0 + lane, W);
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t i = row0 + u * 64 + lane;
+                evs[u] = false;
+                cs[u] = 0;
+                es[u] = 0;
+                if (i < end && i >= 2) {
+                    const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
+                    evs[u] = pc.cls != CLS_IN;
+                    cs[u] = pc.ctx;
+                    es[u] = pc.val;
+                }
+                xy.advance(64, W);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {  // row by row, lane by lane
+                const uint64_t m = __ballot(evs[u]);
+                if (m == 0) continue;
+                if (evs[u]) ring[(qtail + mbcnt(m)) & (RING - 1u)] = (cs[u] << 22) | (es[u] << 13) | (row0 - begin + u * 64 + lane);
+                qtail += (uint32_t)__popcll(m);
+            }
+        }
+    };
+#pragma unroll
+    for (uint32_t d = 0; d < PAIR; d++) issue(pre[d], have[d]);
+    for (uint32_t row0 = begin; row0 < end;) {
+        Interior4<T> now[PAIR];
+        bool inter[PAIR];
+#pragma unroll
+        for (uint32_t d = 0; d < PAIR; d++) {
+            now[d] = pre[d];
+            inter[d] = have[d];
+        }
+#pragma unroll
+        for (uint32_t d = 0; d < PAIR; d++) issue(pre[d], have[d]);  // the next round's loads: in flight during this whole round
+#pragma unroll
+        for (uint32_t d = 0; d < PAIR; d++) {
+            if (row0 < end) {
+                trip(now[d], inter[d], row0);
+                row0 += 256;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        while (qtail - qhead >= 64u) {
+            drain(64u);
+            qhead += 64u;
         }
     }
     if (qtail != qhead) drain(qtail - qhead);

@@ -1,4 +1,4 @@
-# blocking-call time of 64 4K gray8 frames of different content, for the library FELICS_LIB_PATH points at
+# ms per queued step and per blocking call of 64 4K gray8 frames of different content (the library FELICS_LIB_PATH points at, or the tree's)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -15,7 +15,7 @@ def natural(f):
     noise = torch.randn((H, W), device=dev, generator=g) * amp
     return (base + edges + noise).clamp(0, 255).to(torch.uint8)
 kinds = {"S1": lambda f: synth_torch.gray8(W, H, f, "S1", device=dev), "S2 (noise)": lambda f: synth_torch.gray8(W, H, f, "S2", device=dev),
-         "natural-like": natural}
+         "S3 (flat)": lambda f: synth_torch.gray8(W, H, f, "S3", device=dev), "natural-like": natural}
 enc = felics_amd.Encoder(0)
 for name, gen in kinds.items():
     frames = torch.stack([gen(f) for f in range(n)])
@@ -28,6 +28,18 @@ for name, gen in kinds.items():
     for _ in range(R):
         offs, lens = enc.compress_batch_device(frames.data_ptr(), n, W, H, 0, 0, d_out.data_ptr(), cap)
     dt = (time.perf_counter() - t) / R
-    print("%-14s %.3f ms per 64 frames  %.2f bits/pixel" % (name, dt * 1e3, 8.0 * float(sum(lens)) / (n * W * H)), flush=True)
-    del frames, d_out
+    q = enc.lane_count()
+    outs = [d_out] + [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(q - 1)]
+    for i in range(q):
+        enc.wait_batch(enc.submit_batch_device(frames.data_ptr(), n, W, H, 0, 0, outs[i].data_ptr(), cap))
+    torch.cuda.synchronize(); t = time.perf_counter(); K = 16; fl = []
+    for i in range(K):
+        if len(fl) == q:
+            enc.wait_batch(fl.pop(0))
+        fl.append(enc.submit_batch_device(frames.data_ptr(), n, W, H, 0, 0, outs[i % q].data_ptr(), cap))
+    while fl:
+        enc.wait_batch(fl.pop(0))
+    torch.cuda.synchronize(); dq = (time.perf_counter() - t) / K
+    print("%-14s %.3f ms per queued step (%d MPix/s), %.3f ms per blocking call, %.2f bits/pixel" % (name, dq * 1e3, n * W * H / dq / 1e6, dt * 1e3, 8.0 * float(sum(lens)) / (n * W * H)), flush=True)
+    del frames, d_out, outs
 enc.close()

@@ -443,14 +443,14 @@ def main():
             if stage == "pack":
                 if args.depth16:
                     return "k_pack"
-                return {"kernel": "k_pack_fused", "inpack": "k_pack_k"}.get(os.environ.get("FELICS_ASSIGN", ""), "k_pack_g")
+                return "k_pack" if os.environ.get("FELICS_TWO_PASS") else "k_pack_g"
             if stage == "offsets":
                 return "k_tile_offsets"
             if stage == "spine":
-                return "k_spine" if os.environ.get("FELICS_SPINE") == "single" else "k_spine2"
+                return "k_spine2"
             if stage == "zero":
                 return "k_finish_sizes+k_join_edges"
-            if stage == "assign" and os.environ.get("FELICS_ASSIGN", "") not in ("kernel", "inpack") and not args.depth16:
+            if stage == "assign" and not args.depth16:
                 return "k_assign_serial"
             return "k_" + stage
 
@@ -491,7 +491,11 @@ def main():
             by_kernel = {}
             for k, v in stage_ms.items():
                 n = max(1, enc.stage_launches().get(k, 1))
-                if v > 0:
+                if v > 0 and k in ("zero", "offsets"):
+                    # bookkeeping over counts and tile words, not over pixels: the algorithmic pixel bytes do not apply
+                    by_kernel[kernel_of(k)] = {"ms_per_step_sum_of_launches": round(v, 4), "launches_per_step": n,
+                                               "achieved_GBs": None, "frac": None, "note": "reads no pixels"}
+                elif v > 0:
                     g = alg_bytes / n / (v / n * 1e-3) / 1e9
                     by_kernel[kernel_of(k)] = {"ms_per_step_sum_of_launches": round(v, 4), "launches_per_step": n,
                                                "achieved_GBs": round(g, 2), "frac": round(g / HBM_PEAK_GBS, 5)}

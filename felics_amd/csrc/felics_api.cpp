@@ -828,7 +828,7 @@ int felics_ctx_create(int device, felics_ctx **out) {
     // Oldest work first: the spine (the one sequential chain) and the tail, which finishes the submission that is
     // furthest along, go before the front (histogram and scatter of the submission that has just started).  Measured with
     // two submissions in flight: 4.11 / 4.13 ms per step against 4.24 / 4.19 with the front preferred (round 1's choice)
-    // and 4.12 / 4.17 with only the tail preferred; blocking calls do not care.  FELICS_PRIO selects the others.
+    // and 4.12 / 4.17 with only the tail preferred; blocking calls do not care.
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);  // numerically: low >= high
     int prio_spine = prio_high, prio_front = prio_low, prio_tail = prio_high;

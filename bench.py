@@ -216,6 +216,7 @@ def main():
     # queued before step i is waited for, so the GPU classifies / scatters the next batch while it packs the
     # last slices of this one.  Every step runs in full and is complete inside the timed region.
     host_submit_s = 0.0  # host time inside felics_submit_batch_device (queueing a step's launches)
+    stats_before = enc.stats()
     group.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -239,6 +240,11 @@ def main():
     group.barrier()
     elapsed = time.perf_counter() - t0
     enc.set_profiling(False)
+    stats_after = enc.stats()
+    # which of the two event sorts the timed steps used (the context picks by content: felics_api.cpp, scatter_mode)
+    timed_subs = stats_after["submissions"] - stats_before["submissions"]
+    sorted_subs = stats_after["sorted_event_sorts"] - stats_before["sorted_event_sorts"]
+    scatter_kernel = "k_scatter" if timed_subs and 2 * sorted_subs > timed_subs else "k_scatter_ballot"
     # every rank's own figures (skew between ranks, and which device each one ran on), gathered before the MAX
     per_rank = group.gather_objects({"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(local),
                                      "device_index": local, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
@@ -452,6 +458,8 @@ def main():
                 return "k_finish_sizes+k_join_edges"
             if stage == "assign" and not args.depth16:
                 return "k_assign_serial"
+            if stage == "scatter" and not args.depth16:
+                return scatter_kernel
             return "k_" + stage
 
         if dom and stage_ms[dom] > 0:
@@ -518,7 +526,7 @@ def main():
             n = max(1, enc.stage_launches().get(k, 1))
             if v > 0:
                 per_stage[kernel_of(k)] = {"avg_launch_ms": round(v / n, 4), "launches_per_step": n,
-                                       "achieved_GBs": round(alg_bytes / n / (v / n * 1e-3) / 1e9, 2)}
+                                       "achieved_GBs": None if k in ("zero", "offsets") else round(alg_bytes / n / (v / n * 1e-3) / 1e9, 2)}
         pipeline_gbs = alg_bytes / (ms_per_step * 1e-3) / 1e9
         cpu1 = cpum = None
         if args.cpu_seconds > 0:

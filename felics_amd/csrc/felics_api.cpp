@@ -27,6 +27,9 @@ const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "sp
                                      "wide_keys", "wide_sort", "wide_chains"};
 static_assert(ST_COUNT <= FELICS_MAX_STAGES, "felics.h promises at most FELICS_MAX_STAGES stages");
 
+// felics_ctx::scatter_mode: the LDS-sorted event sort from 4.6 bits per sample on with other submissions beside it (its LDS and its
+// barriers cost more there), from 3.4 in a blocking call (profiles/r04/scatter_sweep.txt: where the two kernels' step times cross)
+constexpr uint32_t SCATTER_SORTED_FROM_CENTIBITS_QUEUED = 460, SCATTER_SORTED_FROM_CENTIBITS_ALONE = 340;
 constexpr int SLICES = 12;              // at most; a submission uses lane.nslices of them
 constexpr int EV_PAIRS = SLICES + 2;     // launches of one stage per sub-batch that can be timed
 constexpr int MAX_LANES = 4;            // upper bound of the submissions in flight (felics_submit_batch_device), each with streams and workspace of its own
@@ -77,6 +80,7 @@ struct Lane {
     int r_rc = 0;
     // the sub-batch in flight
     int nslices = SLICES;             // slices its tiles are cut into (see felics_ctx::slices_*)
+    bool queued = false;              // this sub-batch came through felics_submit_batch_device (other submissions share the GPU with it)
     Geometry g;
     size_t first_image = 0;
     const void *d_planes = nullptr;
@@ -104,6 +108,16 @@ struct felics_ctx {
     bool serial = false;        // FELICS_SERIAL=1 (profiling tools: every kernel alone): all stages of a lane on one stream
     bool test_timeout = false;  // FELICS_TEST_TIMEOUT=1: every wait for the GPU reports a time-out (tests of the failed state)
     bool test_lookback = false; // FELICS_TEST_LOOKBACK_FAIL=1: pretend the first single-pass submission gave up (tests)
+    // Which event sort (felics_kernels.hip, scatter).  k_scatter (a tile's events sorted in LDS, written run by run) costs more per
+    // tile and much less per event than k_scatter_ballot (64 events at a time straight to the chains): measured on 64 4K frames
+    // per step, noise 4.1 against 7.8 ms, smooth synthetic frames 3.0 against 2.8, equal at 4.6 bits per pixel; in blocking calls
+    // equal at 3.4 (profiles/r04/scatter_sweep.txt).  The context
+    // picks by what the previous batch compressed to (bits per sample: nothing else about the content is known to the host
+    // before a batch is queued); both produce the same bytes.  FELICS_SCATTER=sorted / ballot pins one.
+    enum ScatterMode { SCATTER_AUTO, SCATTER_SORTED, SCATTER_BALLOT } scatter_mode = SCATTER_AUTO;
+    uint32_t last_centibits = 0;     // bits per sample x 100 of the last batch whose sizes were read (0: none yet)
+    bool scatter_ballot = false;     // k_scatter's order check failed once: k_scatter_ballot from then on, whatever the mode
+    bool test_scatter_order = false; // FELICS_TEST_SCATTER_ORDER=1: k_scatter reports a violation whatever it produced (tests)
     bool poison = false;        // FELICS_POISON=1: overwrite the workspace before every sub-batch (tests)
     bool trace = false;         // FELICS_TRACE=1: synchronise and report after every stage (debugging)
     int timeout_s = 120;        // FELICS_TIMEOUT_S: give up waiting for a submission after this long
@@ -332,6 +346,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         target.scratch = (uint8_t *)l.pscratch.p;
     }
     uint32_t *d_error = (uint32_t *)l.scalars.p + 8;  // look-back watchdog of the single-pass pack
+    uint32_t *d_order = (uint32_t *)l.scalars.p + 9;  // k_scatter's order check (read back together with d_error)
     uint32_t *d_tickets = (uint32_t *)l.scalars.p + 16;  // one per pack launch of this sub-batch: tiles are handed out in order
 
     uint32_t bounds[SLICES + 1];  // slice boundaries in sort tiles (= pack tiles)
@@ -354,12 +369,17 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         HIP_TRY(ctx, hipMemsetAsync(chain_prog, 0, (size_t)g.nplanes * g.nctx * 32, f));
         HIP_TRY(ctx, hipMemsetAsync(l.partial.p, 0, (size_t)ns * g.nplanes * g.nctx * 8, f));
     }
+    HIP_TRY(ctx, hipMemsetAsync(d_order, 0, 4, f));
+    const bool by_ballot = ctx->scatter_ballot || ctx->scatter_mode == felics_ctx::SCATTER_BALLOT ||
+                           (ctx->scatter_mode == felics_ctx::SCATTER_AUTO &&
+                            ctx->last_centibits < (l.queued ? SCATTER_SORTED_FROM_CENTIBITS_QUEUED : SCATTER_SORTED_FROM_CENTIBITS_ALONE));
+    if (!by_ballot) ctx->stats.sorted_event_sorts++;
     for (int q = 0; q < ns; q++) {
         if (bounds[q + 1] != bounds[q]) {
             StageTimer t(ctx, l, ST_SCATTER, f, true);
             // (the single-pass pack knows its tile: pix_of then holds 16-bit offsets into the sort tile)
             launch_scatter<T, ET>(f, d_planes, counts, chain_base, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, fused, g,
-                                  bounds[q], bounds[q + 1]);
+                                  bounds[q], bounds[q + 1], d_order, by_ballot, ctx->test_scatter_order);
         }
         HIP_TRY(ctx, hipEventRecord(l.slice_done[q], f));
     }
@@ -437,7 +457,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(l.h_sizes, l.image_bytes.p, (size_t)g.nimages * 8, hipMemcpyDeviceToHost, tl));
     l.h_sizes[g.nimages] = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&l.h_sizes[g.nimages], d_error, 4, hipMemcpyDeviceToHost, tl));
+    HIP_TRY(ctx, hipMemcpyAsync(&l.h_sizes[g.nimages], d_error, 8, hipMemcpyDeviceToHost, tl));  // d_error | d_order << 32
     HIP_TRY(ctx, hipEventRecord(l.sized, tl));
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(l.span_end, tl));
     return FELICS_OK;
@@ -592,8 +612,9 @@ size_t max_images_per_pass(uint64_t npix, uint32_t planes, int depth) {
 // Queues one sub-batch (cnt frames starting at frame `first` of d_pixels) on a lane: geometry, colour
 // transform, and everything run_lane / run_wide enqueue.  Returns without waiting.
 int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const void *d_pixels, uint32_t w, uint32_t h,
-                     int color, int depth, uint8_t *lane_out, uint64_t slot, int nslices) {
+                     int color, int depth, uint8_t *lane_out, uint64_t slot, int nslices, bool queued = false) {
     l.nslices = std::max(1, std::min(nslices, SLICES));
+    l.queued = queued;
     ctx->stats.submissions++;
     const uint32_t planes = color == FELICS_COLOR_RGB ? 3 : 1;
     const uint64_t npix = (uint64_t)w * h;
@@ -635,17 +656,24 @@ int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const v
 struct SlotOutcome {
     bool lookback_failed = false;  // a tile of the single-pass pack gave up waiting for the tiles before it
     bool overflow = false;         // a stream outgrew its slot, or an RGB plane its scratch slot
+    bool order_violation = false;  // k_scatter's check of its own output failed: nothing of this sub-batch is to be used
+    bool redo() const { return lookback_failed || order_violation; }
 };
 
 SlotOutcome read_sizes(felics_ctx *ctx, Lane &l, bool wide, uint64_t slot, uint64_t *offsets, uint64_t *lens) {
     SlotOutcome o;
     if (!wide && ((l.h_sizes[l.g.nimages] & 1u) != 0 || (ctx->test_lookback && !ctx->two_pass))) o.lookback_failed = true;
     if (!wide && (l.h_sizes[l.g.nimages] & 2u) != 0) o.overflow = true;
+    if (!wide && (l.h_sizes[l.g.nimages] >> 32) != 0) o.order_violation = true;
+    uint64_t bytes = 0;
     for (size_t i = 0; i < l.g.nimages; i++) {
         lens[l.first_image + i] = l.h_sizes[i];
+        bytes += l.h_sizes[i];
         offsets[l.first_image + i] = (uint64_t)(l.first_image + i) * slot;
         if (slot != 0 && l.h_sizes[i] > slot) o.overflow = true;
     }
+    if (!wide && !o.redo() && l.g.nplanes != 0 && l.g.npix != 0)
+        ctx->last_centibits = (uint32_t)std::min<uint64_t>(bytes * 800u / ((uint64_t)l.g.nplanes * l.g.npix), 100000u);
     return o;
 }
 
@@ -665,6 +693,15 @@ void note_lookback_failure(felics_ctx *ctx) {
         ctx->stats.two_pass = 1;
         ctx->err = "a tile gave up waiting for its predecessors: this context now packs with the two-pass kernels (slower)";
     }
+}
+
+// k_scatter ranks a batch of events with one returning LDS atomic and relies on the lanes that name one address being served in
+// lane order -- which this hardware does (profiles/tools/micro/lds_atomic_order.hip) and no document promises; so the kernel
+// checks the order of what it wrote, and a context whose check fails once uses the ballot-ranked kernel from then on.
+void note_scatter_order_violation(felics_ctx *ctx) {
+    ctx->stats.scatter_fallbacks++;
+    ctx->scatter_ballot = true;
+    ctx->err = "k_scatter's order check failed: this context now ranks events with ballots (k_scatter_ballot)";
 }
 
 // Encode `n` same-shape frames resident in device memory into d_out (device), on one lane, and wait.
@@ -726,12 +763,12 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
     }
     if (start_exact) slot = 0;
 
-    for (int attempt = 0; attempt < 4; attempt++) {  // (at most: tickets, two-pass, exact placement, and the run that succeeds)
+    for (int attempt = 0; attempt < 5; attempt++) {  // (at most: ballot scatter, tickets, two-pass, exact placement, and the run that succeeds)
         size_t done = 0;
         uint64_t out_base = 0;  // exact placement: where the next pass's streams start
         SlotOutcome outcome;
         // passes of up to per_pass frames (one pass unless the batch is huge)
-        while (done < n && !outcome.overflow && !outcome.lookback_failed) {
+        while (done < n && !outcome.overflow && !outcome.redo()) {
             const size_t cnt = std::min(per_pass, n - done);
             const size_t first = done + cnt;
             if ((rc = launch_sub_batch(ctx, l, done, cnt, d_pixels, w, h, color, depth, d_out + done * slot, slot, ctx->slices_blocking)) != 0) {
@@ -740,7 +777,7 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
             }
             if ((rc = wait_event(ctx, l.sized, "stream sizes")) != 0) return rc;
             outcome = read_sizes(ctx, l, wide, slot, offsets, lens);
-            if (slot == 0) {
+            if (slot == 0 && !outcome.order_violation) {
                 // exact placement of this pass: back to back, 16-byte aligned, in image order
                 uint64_t need = out_base;
                 for (size_t i = done; i < first; i++) {
@@ -773,9 +810,12 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
             if ((rc = sync_lane(ctx, l)) != 0) return rc;
             done = first;
         }
-        if (outcome.lookback_failed) {
+        if (outcome.redo()) {
             if ((rc = sync_lane(ctx, l)) != 0) return rc;
-            note_lookback_failure(ctx);
+            if (outcome.order_violation)
+                note_scatter_order_violation(ctx);
+            else
+                note_lookback_failure(ctx);
             continue;
         }
         if (!outcome.overflow) break;
@@ -818,6 +858,9 @@ int felics_ctx_create(int device, felics_ctx **out) {
     ctx->poison = getenv("FELICS_POISON") != nullptr;
     ctx->two_pass = getenv("FELICS_TWO_PASS") != nullptr;
     ctx->test_lookback = getenv("FELICS_TEST_LOOKBACK_FAIL") != nullptr;
+    if (const char *e = getenv("FELICS_SCATTER"))
+        ctx->scatter_mode = !strcmp(e, "sorted") ? felics_ctx::SCATTER_SORTED : !strcmp(e, "ballot") ? felics_ctx::SCATTER_BALLOT : felics_ctx::SCATTER_AUTO;
+    ctx->test_scatter_order = getenv("FELICS_TEST_SCATTER_ORDER") != nullptr;
     ctx->pack_tickets = ctx->own_tails = getenv("FELICS_OWN_TAILS") != nullptr;
     ctx->serial = getenv("FELICS_SERIAL") != nullptr;
     ctx->test_timeout = getenv("FELICS_TEST_TIMEOUT") != nullptr;
@@ -964,7 +1007,7 @@ int felics_submit_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels, 
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         for (int i = 0; i < ST_COUNT; i++) l.ev_used[i] = 0;
         l.p_slot = slot;
-        if ((rc = launch_sub_batch(ctx, l, 0, n, d_pixels, w, h, color, depth, l.p_out, slot, ctx->slices_queued)) != 0) {
+        if ((rc = launch_sub_batch(ctx, l, 0, n, d_pixels, w, h, color, depth, l.p_out, slot, ctx->slices_queued, true)) != 0) {
             (void)sync_lane(ctx, l);
             return rc;
         }
@@ -996,19 +1039,21 @@ int felics_wait_batch(felics_ctx *ctx, int ticket, uint64_t *offsets, uint64_t *
     }
     int rc;
     const SlotOutcome o = read_sizes(ctx, l, l.p_depth == FELICS_DEPTH_16, l.p_slot, offsets, lens);
-    if (!o.lookback_failed && !o.overflow) {
+    if (!o.redo() && !o.overflow) {
         collect_timing(ctx, l);
         return FELICS_OK;
     }
     // the rare cases: pack again on this lane, synchronously (two-pass kernels / exact placement)
     if ((rc = sync_lane(ctx, l)) != 0) return rc;
-    if (o.lookback_failed) {
+    if (o.order_violation) {
+        note_scatter_order_violation(ctx);
+    } else if (o.lookback_failed) {
         note_lookback_failure(ctx);
     } else {
         ctx->stats.slot_overflows++;
     }
     return encode_device(ctx, l, l.p_n, l.p_pixels, l.p_w, l.p_h, l.p_color, l.p_depth, l.p_out, l.p_cap, offsets, lens,
-                         nullptr, o.overflow && !o.lookback_failed);
+                         nullptr, o.overflow && !o.redo());
 }
 
 int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, uint32_t w, uint32_t h, int color,

@@ -78,7 +78,11 @@ void launch_offsets(hipStream_t s, uint32_t *counts, uint32_t *chain_len, uint32
 // scatter works on a slice [tile_begin, tile_end) of every plane's tiles
 template <typename T, typename ET>
 void launch_scatter(hipStream_t s, const T *planes, const uint32_t *tile_off, const uint32_t *chain_base,
-                    ET *sorted_e, uint32_t *pix_of, bool in_tile_offsets, const Geometry &g, uint32_t tile_begin, uint32_t tile_end);
+                    ET *sorted_e, uint32_t *pix_of, bool in_tile_offsets, const Geometry &g, uint32_t tile_begin, uint32_t tile_end,
+                    uint32_t *order_flag, bool by_ballot, bool test_violation);
+// Default: a tile's events are sorted in LDS (ranked by returning LDS atomics) and written run by run; the kernel checks the order
+// it produced and sets bit 0 of *order_flag if it is not the stable one -- the caller then redoes the batch with by_ballot (ranks
+// from ballots, stores in raster order; no flag).  test_violation: report a violation whatever the order (tests).
 // pix_of holds, per event slot, where the event's pixel is: plane * npix + i as 32 bits (launch_k_to_pixels writes k by pixel), or
 // -- in_tile_offsets, for launch_pack_g, whose workgroups know their tile -- i - tile * SORT_TILE as 16 bits in the same
 // buffer (launch_zero_padding then gets a null pix_of: the padding slots are never read).

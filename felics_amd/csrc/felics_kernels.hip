@@ -281,14 +281,21 @@ __global__ void k_zero_padding(ET *__restrict__ sorted_e, uint32_t *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// scatter: stable partition of events by context.  One wave per tile walks its pixels in
-// raster order, 64 at a time; lanes that hold the same context rank themselves with a ballot.
+// scatter: stable partition of events by context.
 // sorted_e[slot] = value to Rice-code; pix_of[slot] = the pixel the event came from: plane*npix + i (32 bits) for
 // k_k_to_pixels (two-pass pack), or -- REL, what k_pack_g reads -- the pixel's offset in its sort tile (16 bits, the same buffer).
+//
+// Two kernels.  k_scatter (the default, round 4) sorts a tile's events in LDS and writes every context's run of the tile as
+// one contiguous piece; it ranks with one returning LDS atomic per batch and CHECKS the order it got.  k_scatter_ballot (rounds
+// 1-3) ranks with ballots and stores every batch of 64 events straight to the chains, in raster order: the fallback a context
+// moves to if the check ever fails (felics_api.cpp: note_scatter_order_violation), and what FELICS_SCATTER_BALLOT=1 selects.
+//
+// k_scatter_ballot: one wave per tile walks its pixels in raster order, 64 events at a time; lanes that hold the same context
+// rank themselves with a ballot.
 // ------------------------------------------------------------------------------------------
 
 template <typename T, typename ET, bool REL>
-__global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
+__global__ __launch_bounds__(256) void k_scatter_ballot(const T *__restrict__ planes,
                                                  const uint32_t *__restrict__ tile_off,
                                                  const uint32_t *__restrict__ chain_base,
                                                  ET *__restrict__ sorted_e, uint32_t *__restrict__ pix_of,
@@ -475,6 +482,267 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes,
         }
     }
     if (qtail != qhead) drain(qtail - qhead);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_scatter: one workgroup per tile, a quarter of the tile per wave.
+//
+//   1. every wave classifies its 1024 pixels (all of their loads in flight together: there is no store in this kernel before
+//      its last step, so nothing makes the compiler wait for more than the load it needs) and compacts its events, raster order
+//      kept, into a ring of its own in LDS;
+//   2. it ranks its events within (wave, context): ONE returning LDS add on the counter of the event's context ranks the 64
+//      events of a batch (the lanes that name the same address are served in ascending lane order -- measured over 2 x 10^10
+//      atomics, profiles/tools/micro/lds_atomic_order.hip, and not documented anywhere, hence step 5's check), against nine
+//      ballots and the mask arithmetic around them in k_scatter_ballot; the ranks stay in registers, the counters end as the
+//      wave's event count per context;
+//   3. thread c turns the four waves' counts of context c into the tile's local layout -- contexts in ascending order, within a
+//      context wave 0's events, then wave 1's ... -- i.e. a start per (wave, context), and into the distance between a
+//      context's place in that layout and its place in the chain (tile_off + chain_base, as before);
+//   4. every wave moves its events to their places (start of its context + rank);
+//   5. the workgroup writes the sorted tile out, 256 consecutive events per trip: a context's run is one contiguous piece of
+//      its chain, so the 64 lanes of a store touch the two or three cache lines its runs lie in instead of one or two per
+//      event context (10-20 lines per instruction on smooth content, 64 on noise: the store path was what this kernel waited
+//      for).  Each event is compared with its successor in the sorted tile: (context, pixel offset) must ascend strictly.  That
+//      is exactly "stable partition": the set of events of a context is fixed by the counts, and ascending pixel offsets are
+//      the one raster order of that set.  A violation raises *order_flag; the host then redoes the batch with k_scatter_ballot.
+//
+// Record: context << 22 | value << 13 | pixel offset in the tile (9 + 9 + 13 bits).
+// ------------------------------------------------------------------------------------------
+
+#ifdef FELICS_SCATTER_STAMPS  // diagnostic build (profiles/tools/scatter_stamps.py): s_memtime of wave 0 between the steps
+__device__ unsigned long long g_scatter_stamps[256][16];
+#define SSTAMP(i)                                                   \
+    do {                                                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        st_acc[i] = now_ - st_last;                                 \
+        st_last = now_;                                             \
+    } while (0)
+extern "C" __attribute__((visibility("default"))) int felics_debug_scatter_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scatter_stamps), sizeof(g_scatter_stamps)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long z[256 * 16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_scatter_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define SSTAMP(i)
+#endif
+
+template <typename T, typename ET, bool REL>
+__global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes, const uint32_t *__restrict__ tile_off,
+                                                 const uint32_t *__restrict__ chain_base, ET *__restrict__ sorted_e,
+                                                 uint32_t *__restrict__ pix_of, uint32_t W, uint32_t npix, uint32_t ntiles,
+                                                 uint32_t tile_begin, uint32_t tile_end, uint32_t nplanes,
+                                                 uint32_t *__restrict__ order_flag, uint32_t test_violation) {
+    constexpr uint32_t NC = nctx_of<T>();
+    constexpr uint32_t QUARTER = SORT_TILE / 4, TRIPS = QUARTER / 256;
+    constexpr uint32_t PER = NC / 256;  // contexts per thread in step 3
+    constexpr uint32_t KEY = 0xFFC01FFFu;  // context and pixel offset of a record
+    static_assert(SORT_TILE % 1024 == 0 && SORT_TILE <= (1u << 13), "four whole trips per wave; 13 bits of pixel offset");
+    static_assert(NC % 256 == 0 && NC <= 512, "a thread takes NC / 256 contexts; 9 bits of context");
+    __shared__ uint32_t srt[SORT_TILE + 1];   // the tile's events in chain order (+ a sentinel behind the last)
+    __shared__ uint32_t rings[4][QUARTER];    // every wave's events in raster order
+    __shared__ uint32_t cnt[4][NC];           // per wave and context: count, then cursor into srt
+    __shared__ uint32_t gdst[NC];             // chain slot of a context's run minus the run's place in srt
+    __shared__ uint32_t wsum[4];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();  // (uniform: see k_hist)
+    const uint32_t tid = threadIdx.x;
+#ifdef FELICS_SCATTER_STAMPS
+    unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_acc[10] = {};
+#endif
+    // Workgroup -> (plane, tile), XCD-aware: workgroups are dealt round-robin over the eight XCDs (MI355X_MICROARCH.md,
+    // workgroup dispatch: blocks b and b + 8 share one), and every XCD has an L2 of its own that does not merge its partial
+    // lines with another XCD's.  Neighbouring tiles of a plane append to the same cache lines of every chain, so all tiles of
+    // plane p go to the XCD p % 8 (in tile order: workgroup b = 8 i + x takes item i of XCD x's list of planes x, x + 8, ...) --
+    // the XCD whose spine and pack workgroups read the chains of plane p later (their grids are plane-minor with 64 planes).
+    // Placement only: nothing depends on it for correctness.
+    const uint32_t wg_tiles = tile_end - tile_begin;
+    const uint32_t item = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+    const uint32_t plane = xcd + 8u * (item / wg_tiles);
+    if (plane >= nplanes) return;  // (the whole workgroup)
+    const uint32_t tile = tile_begin + item % wg_tiles;
+    // where the chains continue for this tile: needed in step 3, asked for now
+    uint32_t runpos[PER];
+    {
+        const uint32_t *off = tile_off + ((uint64_t)plane * ntiles + tile) * NC + tid * PER;
+        const uint32_t *cb = chain_base + (uint64_t)plane * NC + tid * PER;
+#pragma unroll
+        for (uint32_t u = 0; u < PER; u++) runpos[u] = off[u] + cb[u];
+    }
+    uint32_t *my_cnt = cnt[wave];
+    for (uint32_t c = lane; c < NC; c += 64) my_cnt[c] = 0;
+    const T *pl = planes + (uint64_t)plane * npix;
+    const uint32_t plane_first = plane * npix;
+    const uint32_t begin = tile * SORT_TILE;
+    const uint32_t qbegin = min(begin + wave * QUARTER, npix);
+    const uint32_t end = min(qbegin + QUARTER, npix);  // of this wave's quarter
+    uint32_t *ring = rings[wave];
+    uint32_t qtail = 0;  // events in the ring (wave-uniform)
+    // ---- 1. classify and compact
+    auto is_interior = [&](uint32_t r, uint32_t x, uint32_t y) { return y > 0 && x + 256 <= W && r + 256 <= end; };  // (a span from the first column included)
+    Interior4<T> pre[TRIPS];
+    bool have[TRIPS];
+    {
+        uint32_t ri = qbegin, yi = qbegin / W, xi = qbegin - yi * W;
+#pragma unroll
+        for (uint32_t d = 0; d < TRIPS; d++) {
+            have[d] = ri < end && is_interior(ri, xi, yi);
+            if (have[d]) load_interior4(pl, ri, W, span_left_index(ri, xi, yi, W), pre[d]);
+            ri += 256;
+            xi += 256;
+            if (xi >= W) {  // (once per image row: scalar division)
+                const uint32_t q = xi / W;
+                yi += q;
+                xi -= q * W;
+            }
+        }
+    }
+    SSTAMP(0);
+#pragma unroll
+    for (uint32_t d = 0; d < TRIPS; d++) {
+        const uint32_t row0 = qbegin + d * 256;
+        if (row0 >= end) break;
+        if (have[d]) {
+            // lane l takes pixels row0 + 4l .. + 3 (two wide loads instead of twelve byte loads); a prefix
+            // sum of the lanes' event counts keeps the ring in raster order
+            const uint32_t off0 = row0 - begin + 4 * lane;
+            PixelClass pc[4];
+            classify_loaded4(pre[d], pc);
+            uint32_t nev = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) nev += pc[j].cls != CLS_IN ? 1u : 0u;
+            const uint32_t incl = wave_incl_scan(nev);
+            uint32_t pos = qtail + incl - nev;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                if (pc[j].cls != CLS_IN) {
+                    ring[pos] = (pc[j].ctx << 22) | (pc[j].val << 13) | (off0 + j);
+                    pos++;
+                }
+            }
+            qtail += readlane(incl, 63);
+        } else {  // (a trip that crosses a row end, lies in the first row or ends the plane: the general neighbour rule)
+            bool evs[4];
+            uint32_t cs[4], es[4];
+            Coord xy;
+            xy.set(row0 + lane, W);
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t i = row0 + u * 64 + lane;
+                evs[u] = false;
+                cs[u] = 0;
+                es[u] = 0;
+                if (i < end && i >= 2) {
+                    const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
+                    evs[u] = pc.cls != CLS_IN;
+                    cs[u] = pc.ctx;
+                    es[u] = pc.val;
+                }
+                xy.advance(64, W);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {  // row by row, lane by lane
+                const uint64_t m = __ballot(evs[u]);
+                if (m == 0) continue;
+                if (evs[u]) ring[qtail + mbcnt(m)] = (cs[u] << 22) | (es[u] << 13) | (row0 - begin + u * 64 + lane);
+                qtail += (uint32_t)__popcll(m);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    SSTAMP(1);
+    // ---- 2. rank within (wave, context): the count of a context is what its cursor ends at.  Event 64 b + lane keeps its rank in
+    // a register (static slots, wave-uniform guards), so the events are named to the LDS atomics once, not twice.
+    // (Batches go in groups of GROUP under one wave-uniform guard: the LDS reads of a group are in flight together, and so are
+    // its atomics -- one batch at a time every batch was two LDS round trips of a wave with nothing else to do.)
+    constexpr uint32_t BATCHES = QUARTER / 64, GROUP = 4;
+    uint32_t rk[BATCHES];
+#pragma unroll
+    for (uint32_t g = 0; g < BATCHES; g += GROUP) {
+#pragma unroll
+        for (uint32_t u = 0; u < GROUP; u++) rk[g + u] = 0;
+        if (g * 64 < qtail) {
+            uint32_t c[GROUP];
+#pragma unroll
+            for (uint32_t u = 0; u < GROUP; u++) c[u] = ring[(g + u) * 64 + lane] >> 22;  // (past qtail: whatever the ring held, not used)
+#pragma unroll
+            for (uint32_t u = 0; u < GROUP; u++)
+                if ((g + u) * 64 + lane < qtail) rk[g + u] = atomicAdd(&my_cnt[c[u]], 1u);
+        }
+    }
+    SSTAMP(2);
+    __syncthreads();
+    SSTAMP(3);
+    // ---- 3. the tile's layout: thread t takes contexts t * PER ..
+    {
+        uint32_t n[4][PER], tot = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < PER; u++) {
+#pragma unroll
+            for (uint32_t w = 0; w < 4; w++) {
+                n[w][u] = cnt[w][tid * PER + u];
+                tot += n[w][u];
+            }
+        }
+        const uint32_t incl = wave_incl_scan(tot);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t at = incl - tot;  // events of the tile in contexts below this thread's
+        for (uint32_t w = 0; w < wave; w++) at += wsum[w];
+#pragma unroll
+        for (uint32_t u = 0; u < PER; u++) {
+            const uint32_t c = tid * PER + u;
+            gdst[c] = runpos[u] - at;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; w++) {
+                cnt[w][c] = at;
+                at += n[w][u];
+            }
+        }
+    }
+    const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (tid == 0) srt[total] = 0xFFFFFFFFu;  // larger than any record's key: the last event has a successor to be compared with
+    __syncthreads();
+    SSTAMP(4);
+    // ---- 4. place: where the context's events of this wave start + the event's rank among them
+#pragma unroll
+    for (uint32_t g = 0; g < BATCHES; g += GROUP) {
+        if (g * 64 < qtail) {
+            uint32_t rec[GROUP], at[GROUP];
+#pragma unroll
+            for (uint32_t u = 0; u < GROUP; u++) rec[u] = ring[(g + u) * 64 + lane];
+#pragma unroll
+            for (uint32_t u = 0; u < GROUP; u++) at[u] = my_cnt[(rec[u] >> 22) & (NC - 1u)] + rk[g + u];  // (masked: past qtail the ring holds anything)
+#pragma unroll
+            for (uint32_t u = 0; u < GROUP; u++)
+                if ((g + u) * 64 + lane < qtail) srt[at[u]] = rec[u];
+        }
+    }
+    SSTAMP(5);
+    __syncthreads();
+    SSTAMP(6);
+    // ---- 5. out, checked
+    uint32_t bad = test_violation;
+    for (uint32_t j = tid; j < total; j += 256) {
+        const uint32_t rec = srt[j], nxt = srt[j + 1];
+        const uint32_t dst = gdst[rec >> 22] + j;
+        sorted_e[dst] = (ET)((rec >> 13) & 0x1FFu);
+        if (REL)  // the pack stage knows its tile: two bytes per event instead of four
+            reinterpret_cast<uint16_t *>(pix_of)[dst] = (uint16_t)(rec & 0x1FFFu);
+        else
+            pix_of[dst] = plane_first + begin + (rec & 0x1FFFu);
+        bad |= (nxt & KEY) <= (rec & KEY) ? 1u : 0u;
+    }
+    if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(order_flag, 1u);
+#ifdef FELICS_SCATTER_STAMPS
+    SSTAMP(7);
+    if (tid == 0) {
+        unsigned long long *slot = g_scatter_stamps[(tile * 7u + plane) & 255u];
+        for (int i = 0; i < 8; i++) atomicAdd(&slot[i], st_acc[i]);
+        atomicAdd(&slot[15], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2194,21 +2462,32 @@ void launch_offsets(hipStream_t s, uint32_t *counts, uint32_t *chain_len, uint32
 
 template <typename T, typename ET>
 void launch_scatter(hipStream_t s, const T *planes, const uint32_t *tile_off, const uint32_t *chain_base,
-                    ET *sorted_e, uint32_t *pix_of, bool in_tile_offsets, const Geometry &g, uint32_t tile_begin, uint32_t tile_end) {
+                    ET *sorted_e, uint32_t *pix_of, bool in_tile_offsets, const Geometry &g, uint32_t tile_begin, uint32_t tile_end,
+                    uint32_t *order_flag, bool by_ballot, bool test_violation) {
     if (tile_end <= tile_begin) return;
-    // one workgroup per four tiles of a plane; the planes are dealt to the XCDs by the kernel (see there)
-    const dim3 grid(8u * cdiv(g.nplanes, 8) * cdiv(tile_end - tile_begin, 4));
+    // the planes are dealt to the XCDs by the kernels (see there)
+    if (by_ballot) {  // one workgroup per four tiles of a plane
+        const dim3 grid(8u * cdiv(g.nplanes, 8) * cdiv(tile_end - tile_begin, 4));
+        if (in_tile_offsets)
+            FELICS_LAUNCH((k_scatter_ballot<T, ET, true>), grid, dim3(256), s, planes, tile_off, chain_base, sorted_e, pix_of, g.W,
+                          g.npix, g.sort_tiles, tile_begin, tile_end, g.nplanes);
+        else
+            FELICS_LAUNCH((k_scatter_ballot<T, ET, false>), grid, dim3(256), s, planes, tile_off, chain_base, sorted_e, pix_of, g.W,
+                          g.npix, g.sort_tiles, tile_begin, tile_end, g.nplanes);
+        return;
+    }
+    const dim3 grid(8u * cdiv(g.nplanes, 8) * (tile_end - tile_begin));  // one workgroup per tile
     if (in_tile_offsets)
         FELICS_LAUNCH((k_scatter<T, ET, true>), grid, dim3(256), s, planes, tile_off, chain_base, sorted_e, pix_of, g.W, g.npix,
-                      g.sort_tiles, tile_begin, tile_end, g.nplanes);
+                      g.sort_tiles, tile_begin, tile_end, g.nplanes, order_flag, test_violation ? 1u : 0u);
     else
         FELICS_LAUNCH((k_scatter<T, ET, false>), grid, dim3(256), s, planes, tile_off, chain_base, sorted_e, pix_of, g.W, g.npix,
-                      g.sort_tiles, tile_begin, tile_end, g.nplanes);
+                      g.sort_tiles, tile_begin, tile_end, g.nplanes, order_flag, test_violation ? 1u : 0u);
 }
 template void launch_scatter<uint8_t, uint8_t>(hipStream_t, const uint8_t *, const uint32_t *, const uint32_t *,
-                                               uint8_t *, uint32_t *, bool, const Geometry &, uint32_t, uint32_t);
+                                               uint8_t *, uint32_t *, bool, const Geometry &, uint32_t, uint32_t, uint32_t *, bool, bool);
 template void launch_scatter<int16_t, uint16_t>(hipStream_t, const int16_t *, const uint32_t *, const uint32_t *,
-                                                uint16_t *, uint32_t *, bool, const Geometry &, uint32_t, uint32_t);
+                                                uint16_t *, uint32_t *, bool, const Geometry &, uint32_t, uint32_t, uint32_t *, bool, bool);
 
 template <typename ET>
 void launch_zero_padding(hipStream_t s, ET *sorted_e, uint32_t *pix_of, const uint32_t *chain_base,

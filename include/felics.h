@@ -161,6 +161,8 @@ typedef struct felics_stats {
     uint64_t lookback_fallbacks; /* batches redone because a tile gave up waiting for its predecessors */
     int two_pass;                /* 1: a ticketed look-back gave up as well: the context packs with the two-pass kernels from now on (slower) */
     int failed;                  /* 1: a wait for the GPU timed out; every further call returns FELICS_E_HIP */
+    uint64_t scatter_fallbacks;  /* 0 or 1: the event sort's check of its own output failed once; the batch was redone and the context ranks events with ballots from then on (slower, no assumption about the LDS) */
+    uint64_t sorted_event_sorts; /* sub-batches of 8-bit samples whose events were sorted by the LDS-sorted kernel (chosen by content: the rest used the ballot-ranked one) */
 } felics_stats;
 int felics_get_stats(const felics_ctx *ctx, felics_stats *out);
 

@@ -55,7 +55,8 @@ X2 = {"k_spine": "x2: uint4 loads of the event blocks",
       "k_pack_g": "raw + input bytes: the 16-byte loads of the pixels (twice the input size: the group and the row above it, counted at half) are its only wide loads; k, offsets and the run table are read as bytes / words / dwords",
       "k_assign_serial": "x2: uint4 loads of the events and the block states",
       "k_hist": "calibrated: raw x (input bytes / k_hist raw): the kernel reads the input exactly once",
-      "k_scatter": "calibrated: raw x (input bytes / k_hist raw): the same unaligned 4-byte loads as k_hist"}
+      "k_scatter": "calibrated: raw x (input bytes / k_hist raw): the same unaligned 4-byte loads as k_hist",
+      "k_scatter_ballot": "calibrated: raw x (input bytes / k_hist raw): the same unaligned 4-byte loads as k_hist"}
 res = {}
 total = 0
 valu_total = 0

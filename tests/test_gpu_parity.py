@@ -282,7 +282,12 @@ def test_pack_variants(oracle):
     # kernels (k to a byte per pixel, lengths, bit scan, pack); FELICS_SERIAL / FELICS_TRACE are the profiling / debugging aids
     for env in ({}, {"FELICS_TWO_PASS": "1"}, {"FELICS_TEST_LOOKBACK_FAIL": "1"}, {"FELICS_OWN_TAILS": "1"},
                 {"FELICS_OWN_TAILS": "1", "FELICS_TEST_LOOKBACK_FAIL": "1"}, {"FELICS_LANES": "1"}, {"FELICS_LANES": "4", "FELICS_SLICES": "12"},
-                {"FELICS_SERIAL": "1", "FELICS_SLICES": "1"}, {"FELICS_TRACE": "1", "FELICS_TIMEOUT_S": "30"}):
+                {"FELICS_SERIAL": "1", "FELICS_SLICES": "1"}, {"FELICS_TRACE": "1", "FELICS_TIMEOUT_S": "30"},
+                # the event sort: ranked with ballots from the start; the default's order check failing once (-> ballots);
+                # and both under the two-pass pack, which reads 32-bit pixel positions from the sort
+                {"FELICS_SCATTER": "ballot"}, {"FELICS_SCATTER": "sorted"}, {"FELICS_SCATTER": "sorted", "FELICS_TEST_SCATTER_ORDER": "1"},
+                {"FELICS_SCATTER": "sorted", "FELICS_TWO_PASS": "1"},
+                {"FELICS_SCATTER": "sorted", "FELICS_TEST_SCATTER_ORDER": "1", "FELICS_TWO_PASS": "1"}):
         os.environ.update(env)
         os.environ["FELICS_POISON"] = "1"
         try:
@@ -301,8 +306,30 @@ def test_pack_variants(oracle):
                 assert st["ticket_retries"] == (0 if "FELICS_OWN_TAILS" in env else 1), (env, st)
             else:
                 assert st["two_pass"] == (1 if "FELICS_TWO_PASS" in env else 0) and st["lookback_fallbacks"] == 0, (env, st)
+            assert st["scatter_fallbacks"] == (1 if "FELICS_TEST_SCATTER_ORDER" in env else 0), (env, st)
         finally:
             e.close()
+
+
+def test_event_sort_follows_content(oracle):
+    """A context sorts the events of a batch with k_scatter_ballot or k_scatter by what the previous batch compressed to
+    (felics_api.cpp: scatter_mode): noise switches it to the LDS-sorted kernel, smooth frames back.  Same bytes either way."""
+    import felics_amd
+    from felics_amd import synth
+
+    noise = [synth.gray8(1000, 700, f, "S2") for f in range(3)]
+    smooth = [synth.gray8(1000, 700, f, "S1") for f in range(3)]
+    rgb = [synth.rgb8(333, 222, f) for f in range(2)]
+    e = felics_amd.Encoder(0)
+    try:
+        for frames in (noise, noise, smooth, rgb, smooth, noise, rgb, rgb):
+            assert e.compress_batch(frames) == [oracle.compress(f) for f in frames]
+        st = e.stats()
+        assert st["scatter_fallbacks"] == 0 and st["lookback_fallbacks"] == 0, st
+        # the first batch of a context goes to the ballot kernel (nothing known yet), the batch after noise to the sorted one
+        assert 0 < st["sorted_event_sorts"] < st["submissions"], st
+    finally:
+        e.close()
 
 
 def test_sixteen_bit_lane_replay(oracle):

@@ -27,9 +27,10 @@ const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "sp
                                      "wide_keys", "wide_sort", "wide_chains"};
 static_assert(ST_COUNT <= FELICS_MAX_STAGES, "felics.h promises at most FELICS_MAX_STAGES stages");
 
-// felics_ctx::scatter_mode: the LDS-sorted event sort from 4.6 bits per sample on with other submissions beside it (its LDS and its
-// barriers cost more there), from 3.4 in a blocking call (profiles/r04/scatter_sweep.txt: where the two kernels' step times cross)
-constexpr uint32_t SCATTER_SORTED_FROM_CENTIBITS_QUEUED = 460, SCATTER_SORTED_FROM_CENTIBITS_ALONE = 340;
+// felics_ctx::scatter_mode: the ballot-ranked event sort only for queued submissions behind a batch that compressed below 3.6 bits
+// per sample (profiles/r04/scatter_sweep.txt: where the two kernels' step times cross in the queue; in blocking calls the
+// LDS-sorted kernel is at least as fast at every content measured)
+constexpr uint32_t SCATTER_BALLOT_BELOW_CENTIBITS_QUEUED = 360;
 constexpr int SLICES = 12;              // at most; a submission uses lane.nslices of them
 constexpr int EV_PAIRS = SLICES + 2;     // launches of one stage per sub-batch that can be timed
 constexpr int MAX_LANES = 4;            // upper bound of the submissions in flight (felics_submit_batch_device), each with streams and workspace of its own
@@ -108,12 +109,13 @@ struct felics_ctx {
     bool serial = false;        // FELICS_SERIAL=1 (profiling tools: every kernel alone): all stages of a lane on one stream
     bool test_timeout = false;  // FELICS_TEST_TIMEOUT=1: every wait for the GPU reports a time-out (tests of the failed state)
     bool test_lookback = false; // FELICS_TEST_LOOKBACK_FAIL=1: pretend the first single-pass submission gave up (tests)
-    // Which event sort (felics_kernels.hip, scatter).  k_scatter (a tile's events sorted in LDS, written run by run) costs more per
-    // tile and much less per event than k_scatter_ballot (64 events at a time straight to the chains): measured on 64 4K frames
-    // per step, noise 4.1 against 7.8 ms, smooth synthetic frames 3.0 against 2.8, equal at 4.6 bits per pixel; in blocking calls
-    // equal at 3.4 (profiles/r04/scatter_sweep.txt).  The context
-    // picks by what the previous batch compressed to (bits per sample: nothing else about the content is known to the host
-    // before a batch is queued); both produce the same bytes.  FELICS_SCATTER=sorted / ballot pins one.
+    // Which event sort (felics_kernels.hip, scatter).  k_scatter (a tile's events sorted in LDS, written run by run) is the
+    // default: 64 4K frames per step, noise 4.0 against 8.1 ms of k_scatter_ballot (64 events at a time straight to the chains),
+    // the headline's synthetic frames 2.8 against 2.8, blocking calls 3.55-3.7 against 3.7-3.85.  Where the events of a batch of 64
+    // crowd into three or four contexts (a smooth surface with little noise: below 3.6 bits per pixel) its LDS atomics serialise
+    // and the ballot kernel is 13-25 % faster in the queue (profiles/r04/scatter_sweep.txt): a context uses it for a queued
+    // submission when the previous batch compressed below that (bits per sample is all the host knows about content before a
+    // batch is queued).  Both produce the same bytes.  FELICS_SCATTER=sorted / ballot pins one.
     enum ScatterMode { SCATTER_AUTO, SCATTER_SORTED, SCATTER_BALLOT } scatter_mode = SCATTER_AUTO;
     uint32_t last_centibits = 0;     // bits per sample x 100 of the last batch whose sizes were read (0: none yet)
     bool scatter_ballot = false;     // k_scatter's order check failed once: k_scatter_ballot from then on, whatever the mode
@@ -371,8 +373,8 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     }
     HIP_TRY(ctx, hipMemsetAsync(d_order, 0, 4, f));
     const bool by_ballot = ctx->scatter_ballot || ctx->scatter_mode == felics_ctx::SCATTER_BALLOT ||
-                           (ctx->scatter_mode == felics_ctx::SCATTER_AUTO &&
-                            ctx->last_centibits < (l.queued ? SCATTER_SORTED_FROM_CENTIBITS_QUEUED : SCATTER_SORTED_FROM_CENTIBITS_ALONE));
+                           (ctx->scatter_mode == felics_ctx::SCATTER_AUTO && l.queued && ctx->last_centibits != 0 &&
+                            ctx->last_centibits < SCATTER_BALLOT_BELOW_CENTIBITS_QUEUED);
     if (!by_ballot) ctx->stats.sorted_event_sorts++;
     for (int q = 0; q < ns; q++) {
         if (bounds[q + 1] != bounds[q]) {

@@ -488,10 +488,10 @@ __global__ __launch_bounds__(256) void k_scatter_ballot(const T *__restrict__ pl
 // k_scatter: one workgroup per tile, a quarter of the tile per wave.
 //
 //   1. every wave classifies its 1024 pixels (all of their loads in flight together: there is no store in this kernel before
-//      its last step, so nothing makes the compiler wait for more than the load it needs) and compacts its events, raster order
-//      kept, into a ring of its own in LDS;
-//   2. it ranks its events within (wave, context): ONE returning LDS add on the counter of the event's context ranks the 64
-//      events of a batch (the lanes that name the same address are served in ascending lane order -- measured over 2 x 10^10
+//      its last step, so nothing makes the compiler wait for more than the load it needs), a trip of 256 at a time: the trip's
+//      events are compacted, raster order kept, into a staging buffer in LDS and read back, 64 per batch, into registers;
+//   2. it ranks its events within (wave, context), batch by batch as they arrive: ONE returning LDS add on the counter of the
+//      event's context ranks the 64 events of a batch (the lanes that name the same address are served in ascending lane order -- measured over 2 x 10^10
 //      atomics, profiles/tools/micro/lds_atomic_order.hip, and not documented anywhere, hence step 5's check), against nine
 //      ballots and the mask arithmetic around them in k_scatter_ballot; the ranks stay in registers, the counters end as the
 //      wave's event count per context;
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes, c
     static_assert(SORT_TILE % 1024 == 0 && SORT_TILE <= (1u << 13), "four whole trips per wave; 13 bits of pixel offset");
     static_assert(NC % 256 == 0 && NC <= 512, "a thread takes NC / 256 contexts; 9 bits of context");
     __shared__ uint32_t srt[SORT_TILE + 1];   // the tile's events in chain order (+ a sentinel behind the last)
-    __shared__ uint32_t rings[4][QUARTER];    // every wave's events in raster order
+    __shared__ uint32_t stages[4][256];       // per wave: the events of one trip in raster order, on their way into registers
     __shared__ uint32_t cnt[4][NC];           // per wave and context: count, then cursor into srt
     __shared__ uint32_t gdst[NC];             // chain slot of a context's run minus the run's place in srt
     __shared__ uint32_t wsum[4];
@@ -577,9 +577,14 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes, c
     const uint32_t begin = tile * SORT_TILE;
     const uint32_t qbegin = min(begin + wave * QUARTER, npix);
     const uint32_t end = min(qbegin + QUARTER, npix);  // of this wave's quarter
-    uint32_t *ring = rings[wave];
-    uint32_t qtail = 0;  // events in the ring (wave-uniform)
-    // ---- 1. classify and compact
+    uint32_t *stage = stages[wave];
+    // ---- 1. classify, compact, rank.  The events of a trip are compacted, raster order kept, into the wave's staging buffer and
+    // read back 64 at a time into registers: event 64 u + lane of trip d lives in slot (d, u) of this lane -- static slots under
+    // wave-uniform guards -- together with its rank within (wave, context), which ONE returning LDS add per 64 events hands out
+    // (the counter of a context ends as the wave's number of events in it).  The batches of a trip go in pairs: their LDS reads
+    // are in flight together, and so are their atomics.
+    constexpr uint32_t BPT = 4, SLOTS = TRIPS * BPT;  // up to 256 events per trip
+    uint32_t rec[SLOTS], rk[SLOTS], nd[TRIPS];
     auto is_interior = [&](uint32_t r, uint32_t x, uint32_t y) { return y > 0 && x + 256 <= W && r + 256 <= end; };  // (a span from the first column included)
     Interior4<T> pre[TRIPS];
     bool have[TRIPS];
@@ -602,75 +607,73 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes, c
 #pragma unroll
     for (uint32_t d = 0; d < TRIPS; d++) {
         const uint32_t row0 = qbegin + d * 256;
-        if (row0 >= end) break;
-        if (have[d]) {
-            // lane l takes pixels row0 + 4l .. + 3 (two wide loads instead of twelve byte loads); a prefix
-            // sum of the lanes' event counts keeps the ring in raster order
-            const uint32_t off0 = row0 - begin + 4 * lane;
-            PixelClass pc[4];
-            classify_loaded4(pre[d], pc);
-            uint32_t nev = 0;
+        nd[d] = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++) nev += pc[j].cls != CLS_IN ? 1u : 0u;
-            const uint32_t incl = wave_incl_scan(nev);
-            uint32_t pos = qtail + incl - nev;
+        for (uint32_t u = 0; u < BPT; u++) rec[d * BPT + u] = rk[d * BPT + u] = 0;
+        if (row0 < end) {
+            uint32_t n = 0;  // events of this trip (wave-uniform)
+            if (have[d]) {
+                // lane l takes pixels row0 + 4l .. + 3 (two wide loads instead of twelve byte loads); a prefix
+                // sum of the lanes' event counts keeps the raster order
+                const uint32_t off0 = row0 - begin + 4 * lane;
+                PixelClass pc[4];
+                classify_loaded4(pre[d], pc);
+                uint32_t nev = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                if (pc[j].cls != CLS_IN) {
-                    ring[pos] = (pc[j].ctx << 22) | (pc[j].val << 13) | (off0 + j);
-                    pos++;
+                for (uint32_t j = 0; j < 4; j++) nev += pc[j].cls != CLS_IN ? 1u : 0u;
+                const uint32_t incl = wave_incl_scan(nev);
+                uint32_t pos = incl - nev;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    if (pc[j].cls != CLS_IN) {
+                        stage[pos] = (pc[j].ctx << 22) | (pc[j].val << 13) | (off0 + j);
+                        pos++;
+                    }
+                }
+                n = readlane(incl, 63);
+            } else {  // (a trip that crosses a row end, lies in the first row or ends the plane: the general neighbour rule)
+                bool evs[4];
+                uint32_t cs[4], es[4];
+                Coord xy;
+                xy.set(row0 + lane, W);
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {
+                    const uint32_t i = row0 + u * 64 + lane;
+                    evs[u] = false;
+                    cs[u] = 0;
+                    es[u] = 0;
+                    if (i < end && i >= 2) {
+                        const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
+                        evs[u] = pc.cls != CLS_IN;
+                        cs[u] = pc.ctx;
+                        es[u] = pc.val;
+                    }
+                    xy.advance(64, W);
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {  // row by row, lane by lane
+                    const uint64_t m = __ballot(evs[u]);
+                    if (m == 0) continue;
+                    if (evs[u]) stage[n + mbcnt(m)] = (cs[u] << 22) | (es[u] << 13) | (row0 - begin + u * 64 + lane);
+                    n += (uint32_t)__popcll(m);
                 }
             }
-            qtail += readlane(incl, 63);
-        } else {  // (a trip that crosses a row end, lies in the first row or ends the plane: the general neighbour rule)
-            bool evs[4];
-            uint32_t cs[4], es[4];
-            Coord xy;
-            xy.set(row0 + lane, W);
+            nd[d] = n;
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t i = row0 + u * 64 + lane;
-                evs[u] = false;
-                cs[u] = 0;
-                es[u] = 0;
-                if (i < end && i >= 2) {
-                    const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
-                    evs[u] = pc.cls != CLS_IN;
-                    cs[u] = pc.ctx;
-                    es[u] = pc.val;
+            for (uint32_t h = 0; h < BPT; h += 2) {
+                if (h * 64 < n) {
+#pragma unroll
+                    for (uint32_t u = h; u < h + 2; u++) rec[d * BPT + u] = stage[u * 64 + lane];  // (past n: whatever the buffer held, not used)
+#pragma unroll
+                    for (uint32_t u = h; u < h + 2; u++)
+                        if (u * 64 + lane < n) rk[d * BPT + u] = atomicAdd(&my_cnt[rec[d * BPT + u] >> 22], 1u);
                 }
-                xy.advance(64, W);
             }
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {  // row by row, lane by lane
-                const uint64_t m = __ballot(evs[u]);
-                if (m == 0) continue;
-                if (evs[u]) ring[qtail + mbcnt(m)] = (cs[u] << 22) | (es[u] << 13) | (row0 - begin + u * 64 + lane);
-                qtail += (uint32_t)__popcll(m);
-            }
+            __builtin_amdgcn_wave_barrier();  // (the next trip writes the staging buffer again)
         }
     }
-    __builtin_amdgcn_wave_barrier();
     SSTAMP(1);
-    // ---- 2. rank within (wave, context): the count of a context is what its cursor ends at.  Event 64 b + lane keeps its rank in
-    // a register (static slots, wave-uniform guards), so the events are named to the LDS atomics once, not twice.
-    // (Batches go in groups of GROUP under one wave-uniform guard: the LDS reads of a group are in flight together, and so are
-    // its atomics -- one batch at a time every batch was two LDS round trips of a wave with nothing else to do.)
-    constexpr uint32_t BATCHES = QUARTER / 64, GROUP = 4;
-    uint32_t rk[BATCHES];
-#pragma unroll
-    for (uint32_t g = 0; g < BATCHES; g += GROUP) {
-#pragma unroll
-        for (uint32_t u = 0; u < GROUP; u++) rk[g + u] = 0;
-        if (g * 64 < qtail) {
-            uint32_t c[GROUP];
-#pragma unroll
-            for (uint32_t u = 0; u < GROUP; u++) c[u] = ring[(g + u) * 64 + lane] >> 22;  // (past qtail: whatever the ring held, not used)
-#pragma unroll
-            for (uint32_t u = 0; u < GROUP; u++)
-                if ((g + u) * 64 + lane < qtail) rk[g + u] = atomicAdd(&my_cnt[c[u]], 1u);
-        }
-    }
     SSTAMP(2);
     __syncthreads();
     SSTAMP(3);
@@ -707,16 +710,18 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes, c
     SSTAMP(4);
     // ---- 4. place: where the context's events of this wave start + the event's rank among them
 #pragma unroll
-    for (uint32_t g = 0; g < BATCHES; g += GROUP) {
-        if (g * 64 < qtail) {
-            uint32_t rec[GROUP], at[GROUP];
+    for (uint32_t d = 0; d < TRIPS; d++) {
 #pragma unroll
-            for (uint32_t u = 0; u < GROUP; u++) rec[u] = ring[(g + u) * 64 + lane];
+        for (uint32_t h = 0; h < BPT; h += 2) {
+            if (h * 64 < nd[d]) {
+                uint32_t at[2];
 #pragma unroll
-            for (uint32_t u = 0; u < GROUP; u++) at[u] = my_cnt[(rec[u] >> 22) & (NC - 1u)] + rk[g + u];  // (masked: past qtail the ring holds anything)
+                for (uint32_t u = 0; u < 2; u++)
+                    at[u] = my_cnt[(rec[d * BPT + h + u] >> 22) & (NC - 1u)] + rk[d * BPT + h + u];  // (masked: an unused slot holds anything)
 #pragma unroll
-            for (uint32_t u = 0; u < GROUP; u++)
-                if ((g + u) * 64 + lane < qtail) srt[at[u]] = rec[u];
+                for (uint32_t u = 0; u < 2; u++)
+                    if ((h + u) * 64 + lane < nd[d]) srt[at[u]] = rec[d * BPT + h + u];
+            }
         }
     }
     SSTAMP(5);

@@ -32,7 +32,7 @@ lib.felics_debug_scatter_stamps(buf, 0)
 a = np.array(list(buf), dtype=np.float64).reshape(256, 16)
 v = list(a.sum(0))
 cnt = v[15]
-names = ["chain positions asked for, counters zeroed, pixel loads issued", "wait for the pixels, classify, compact (4 trips)", "rank (returning LDS adds)", "barrier",
+names = ["chain positions asked for, counters zeroed, pixel loads issued", "wait for the pixels, classify, compact, rank (4 trips)", "-", "barrier",
          "layout (scan, starts) + 2 barriers", "place (start + rank)", "barrier", "out (stores, check)"]
 print("%s: blocking call %.3f ms; %d tiles stamped; s_memtime ticks per tile (thread 0):" % (kind, dt * 1e3, cnt))
 tot = sum(v[:8])

@@ -312,22 +312,38 @@ def test_pack_variants(oracle):
 
 
 def test_event_sort_follows_content(oracle):
-    """A context sorts the events of a batch with k_scatter_ballot or k_scatter by what the previous batch compressed to
-    (felics_api.cpp: scatter_mode): noise switches it to the LDS-sorted kernel, smooth frames back.  Same bytes either way."""
+    """A context sorts the events of a queued submission with k_scatter_ballot when the previous batch compressed below 3.6 bits
+    per sample, and with k_scatter (the default, always in blocking calls) otherwise (felics_api.cpp: scatter_mode).  Same bytes
+    either way."""
+    import torch
     import felics_amd
     from felics_amd import synth
 
+    flat = [np.full((700, 1000), 7 + f, dtype=np.uint8) for f in range(3)]      # 1 bit per pixel
     noise = [synth.gray8(1000, 700, f, "S2") for f in range(3)]
     smooth = [synth.gray8(1000, 700, f, "S1") for f in range(3)]
-    rgb = [synth.rgb8(333, 222, f) for f in range(2)]
     e = felics_amd.Encoder(0)
     try:
-        for frames in (noise, noise, smooth, rgb, smooth, noise, rgb, rgb):
-            assert e.compress_batch(frames) == [oracle.compress(f) for f in frames]
+        assert e.compress_batch(flat) == [oracle.compress(f) for f in flat]      # blocking: sorted whatever the content
+        assert e.stats()["sorted_event_sorts"] == e.stats()["submissions"]
+        seq = (flat, flat, noise, noise, flat, noise, smooth)
+        cap = 1000 * 700 * 3 * 2
+        d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        used_ballot = 0
+        for frames in seq:
+            before = e.stats()
+            d_in = torch.from_numpy(np.stack(frames)).cuda()
+            torch.cuda.synchronize()
+            offs, lens = e.wait_batch(e.submit_batch_device(d_in.data_ptr(), len(frames), 1000, 700, 0, 0, d_out.data_ptr(), cap))
+            host = d_out.cpu().numpy()
+            for i, f in enumerate(frames):
+                assert host[int(offs[i]): int(offs[i] + lens[i])].tobytes() == oracle.compress(f)
+            after = e.stats()
+            used_ballot += (after["submissions"] - before["submissions"]) - (after["sorted_event_sorts"] - before["sorted_event_sorts"])
+        # behind a flat batch -- submissions 1, 2, 3 and 6 of `seq` -- the ballot kernel
+        assert used_ballot == 4, (used_ballot, e.stats())
         st = e.stats()
         assert st["scatter_fallbacks"] == 0 and st["lookback_fallbacks"] == 0, st
-        # the first batch of a context goes to the ballot kernel (nothing known yet), the batch after noise to the sorted one
-        assert 0 < st["sorted_event_sorts"] < st["submissions"], st
     finally:
         e.close()
 

@@ -97,11 +97,8 @@ struct felics_ctx {
     // spine closely.  With two submissions in flight the other batch keeps the GPU busy, and every slice costs
     // a launch and a hand-over per stage: few slices are faster there (measured: 12 -> 5.3, 6 -> 5.1, 3 -> 4.8 ms).
     int slices_blocking = 6;    // FELICS_SLICES
-#ifdef FELICS_EXP_SLICES_QUEUED
-    int slices_queued = FELICS_EXP_SLICES_QUEUED;
-#else
-    int slices_queued = 4;      // (round 3 measured 2-4 lanes x 1-6 slices within 3 % of each other: profiles/r03/experiments.txt)
-#endif
+    int slices_queued = 4;      // (round 3 measured 2-4 lanes x 1-6 slices within 3 % of each other: profiles/r03/experiments.txt;
+                                // round 4, with k_scatter: 2 slices 2.94, 3 2.82-2.89, 4 2.78-2.80, 6 2.89-2.91, 8 2.96 ms; three lanes 3.06)
     // k_pack_g takes its tiles from the workgroup index while the lanes share the tail stream: one pack kernel then has the
     // look-back to itself.  With a tail stream per lane (FELICS_OWN_TAILS=1), and after a look-back has given up once, tiles are
     // handed out by a ticket counter instead: a tile then only ever waits for tiles held by workgroups that are already running,

@@ -551,9 +551,6 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes, c
 #ifdef FELICS_SCATTER_STAMPS
     unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_acc[10] = {};
 #endif
-#ifdef FELICS_EXP_SCATTER_PRIO
-    __builtin_amdgcn_s_setprio(FELICS_EXP_SCATTER_PRIO);
-#endif
     // Workgroup -> (plane, tile), XCD-aware: workgroups are dealt round-robin over the eight XCDs (MI355X_MICROARCH.md,
     // workgroup dispatch: blocks b and b + 8 share one), and every XCD has an L2 of its own that does not merge its partial
     // lines with another XCD's.  Neighbouring tiles of a plane append to the same cache lines of every chain, so all tiles of

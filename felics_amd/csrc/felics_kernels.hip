@@ -607,10 +607,8 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes, c
 #pragma unroll
     for (uint32_t d = 0; d < TRIPS; d++) {
         const uint32_t row0 = qbegin + d * 256;
-        nd[d] = 0;
-#pragma unroll
-        for (uint32_t u = 0; u < BPT; u++) rec[d * BPT + u] = rk[d * BPT + u] = 0;
-        if (row0 < end) {
+        {   // (a trip past the quarter's end takes the general path with every lane switched off: no guard around the trip, so
+            // that the slots are plain assignments and not values merged across a branch -- those cost a register copy each)
             uint32_t n = 0;  // events of this trip (wave-uniform)
             if (have[d]) {
                 // lane l takes pixels row0 + 4l .. + 3 (two wide loads instead of twelve byte loads); a prefix
@@ -661,14 +659,12 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes, c
             nd[d] = n;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (uint32_t h = 0; h < BPT; h += 2) {
-                if (h * 64 < n) {
+            for (uint32_t u = 0; u < BPT; u++) rec[d * BPT + u] = stage[u * 64 + lane];  // (past n: whatever the buffer held, not used)
 #pragma unroll
-                    for (uint32_t u = h; u < h + 2; u++) rec[d * BPT + u] = stage[u * 64 + lane];  // (past n: whatever the buffer held, not used)
-#pragma unroll
-                    for (uint32_t u = h; u < h + 2; u++)
-                        if (u * 64 + lane < n) rk[d * BPT + u] = atomicAdd(&my_cnt[rec[d * BPT + u] >> 22], 1u);
-                }
+            for (uint32_t u = 0; u < BPT; u++) {
+                uint32_t r = 0;
+                if (u * 64 + lane < n) r = atomicAdd(&my_cnt[rec[d * BPT + u] >> 22], 1u);
+                rk[d * BPT + u] = r;
             }
             __builtin_amdgcn_wave_barrier();  // (the next trip writes the staging buffer again)
         }

@@ -529,8 +529,9 @@ extern "C" __attribute__((visibility("default"))) int felics_debug_scatter_stamp
 #define SSTAMP(i)
 #endif
 
+// (six workgroups per CU is what the LDS allows -- five for Y / Co / Cg planes -- and the registers are held to that)
 template <typename T, typename ET, bool REL>
-__global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes, const uint32_t *__restrict__ tile_off,
+__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 5))) __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes, const uint32_t *__restrict__ tile_off,
                                                  const uint32_t *__restrict__ chain_base, ET *__restrict__ sorted_e,
                                                  uint32_t *__restrict__ pix_of, uint32_t W, uint32_t npix, uint32_t ntiles,
                                                  uint32_t tile_begin, uint32_t tile_end, uint32_t nplanes,
@@ -704,21 +705,17 @@ __global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ planes, c
     if (tid == 0) srt[total] = 0xFFFFFFFFu;  // larger than any record's key: the last event has a successor to be compared with
     __syncthreads();
     SSTAMP(4);
-    // ---- 4. place: where the context's events of this wave start + the event's rank among them
+    // ---- 4. place: where the context's events of this wave start + the event's rank among them.  (Lane masks only, no guards: the
+    // LDS reads of eight slots are in flight together, then their writes -- under a guard per pair of slots this step was eight
+    // LDS round trips one after the other.)
 #pragma unroll
-    for (uint32_t d = 0; d < TRIPS; d++) {
+    for (uint32_t q0 = 0; q0 < SLOTS; q0 += 8) {  // (eight slots at a time: sixteen would cost the registers of a sixth workgroup per CU)
+        uint32_t at[8];
 #pragma unroll
-        for (uint32_t h = 0; h < BPT; h += 2) {
-            if (h * 64 < nd[d]) {
-                uint32_t at[2];
+        for (uint32_t q = 0; q < 8; q++) at[q] = my_cnt[(rec[q0 + q] >> 22) & (NC - 1u)];  // (masked: an unused slot holds anything)
 #pragma unroll
-                for (uint32_t u = 0; u < 2; u++)
-                    at[u] = my_cnt[(rec[d * BPT + h + u] >> 22) & (NC - 1u)] + rk[d * BPT + h + u];  // (masked: an unused slot holds anything)
-#pragma unroll
-                for (uint32_t u = 0; u < 2; u++)
-                    if ((h + u) * 64 + lane < nd[d]) srt[at[u]] = rec[d * BPT + h + u];
-            }
-        }
+        for (uint32_t q = 0; q < 8; q++)
+            if (((q0 + q) % BPT) * 64 + lane < nd[(q0 + q) / BPT]) srt[at[q] + rk[q0 + q]] = rec[q0 + q];
     }
     SSTAMP(5);
     __syncthreads();

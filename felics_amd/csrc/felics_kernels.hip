@@ -2268,7 +2268,7 @@ struct GSources {
 };
 
 template <typename T>
-__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 5))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_g(const T *__restrict__ planes, GSources gs, FusedArgs fa,
+__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 6))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_g(const T *__restrict__ planes, GSources gs, FusedArgs fa,
                                                                                                uint32_t sort_tile_begin, uint32_t pack_tile_end) {
     __shared__ alignas(16) uint8_t kq[PACK_TILE];  // k of pixel tile_first + j (event pixels only: the others hold what was there)
     __shared__ FusedLDS fl;

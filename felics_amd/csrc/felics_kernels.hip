@@ -954,10 +954,10 @@ extern "C" __attribute__((visibility("default"))) int felics_debug_spine_stamps(
 #define SCOUNT(i)
 #endif
 
-#ifndef FELICS_SP_BATCH
-#define FELICS_SP_BATCH 16  // (round 4: 8 -> 16: blocking calls 3.70 -> 3.54 ms, the queued step 2.78 -> 2.75; 24 and 32 are faster alone and slower in the queue: LDS)
-#endif
-constexpr uint32_t SP_BATCH = FELICS_SP_BATCH;    // blocks per hand-over
+// Blocks per hand-over (the kernel's template parameter SP_BATCH).  Sixteen for batches (round 4: 64 frames per blocking call 3.70 ->
+// 3.54 ms, the queued step 2.78 -> 2.75; 24 and 32 are faster alone and slower in the queue: LDS), eight for a few planes, where the
+// walker's first wait counts (one 4K frame 2.50 against 2.63 ms with sixteen).
+constexpr uint32_t SP_BATCH_FEW_PLANES = 8, SP_BATCH_MANY_PLANES = 16, SP_MANY_PLANES = 16;
 #ifndef FELICS_SP_HELPERS
 #define FELICS_SP_HELPERS 3
 #endif
@@ -972,7 +972,7 @@ __device__ __forceinline__ bool pk_all_ge(uint32_t p, uint32_t theta) {
     return __builtin_bit_cast(uint32_t, m) == p;
 }
 
-template <typename ET>
+template <typename ET, uint32_t SP_BATCH>
 __global__ __launch_bounds__(64 * (1 + SP_HELPERS)) void k_spine2(const ET *__restrict__ sorted_e, uint32_t *__restrict__ block_state,
                                                 const uint32_t *__restrict__ chain_base,
                                                 const uint32_t *__restrict__ chain_len, uint32_t nchains,
@@ -2507,10 +2507,14 @@ void launch_spine(hipStream_t s, const ET *sorted_e, uint32_t *block_state, cons
                   const uint32_t *chain_len, const uint32_t *tile_off, uint32_t t_end, uint32_t *chain_prog,
                   uint32_t *block_tag, uint32_t *partial, uint32_t epoch, uint32_t slice, const Geometry &g) {
     const uint32_t nchains = g.nplanes * g.nctx;
-    FELICS_LAUNCH((k_spine2<ET>), dim3(nchains), dim3(64 * (1 + SP_HELPERS)), s, sorted_e, block_state, chain_base, chain_len,
-                       nchains, tile_off, g.sort_tiles, t_end, chain_prog, block_tag,
-                       reinterpret_cast<uint2 *>(partial) + (uint64_t)(slice - 1) * nchains,
-                       (epoch << TAG_SLICE_BITS) | slice);
+    uint2 *part = reinterpret_cast<uint2 *>(partial) + (uint64_t)(slice - 1) * nchains;
+    const uint32_t stamp = (epoch << TAG_SLICE_BITS) | slice;
+    if (g.nplanes >= SP_MANY_PLANES)
+        FELICS_LAUNCH((k_spine2<ET, SP_BATCH_MANY_PLANES>), dim3(nchains), dim3(64 * (1 + SP_HELPERS)), s, sorted_e, block_state, chain_base,
+                      chain_len, nchains, tile_off, g.sort_tiles, t_end, chain_prog, block_tag, part, stamp);
+    else
+        FELICS_LAUNCH((k_spine2<ET, SP_BATCH_FEW_PLANES>), dim3(nchains), dim3(64 * (1 + SP_HELPERS)), s, sorted_e, block_state, chain_base,
+                      chain_len, nchains, tile_off, g.sort_tiles, t_end, chain_prog, block_tag, part, stamp);
 }
 template void launch_spine<uint8_t>(hipStream_t, const uint8_t *, uint32_t *, const uint32_t *, const uint32_t *,
                                     const uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t,

@@ -241,10 +241,8 @@ def main():
     elapsed = time.perf_counter() - t0
     enc.set_profiling(False)
     stats_after = enc.stats()
-    # which of the two event sorts the timed steps used (the context picks by content: felics_api.cpp, scatter_mode)
-    timed_subs = stats_after["submissions"] - stats_before["submissions"]
-    sorted_subs = stats_after["sorted_event_sorts"] - stats_before["sorted_event_sorts"]
-    scatter_kernel = "k_scatter" if timed_subs and 2 * sorted_subs > timed_subs else "k_scatter_ballot"
+    # what the timed steps had to redo, if anything (felics_stats: each is a whole batch done again)
+    redone = {k: stats_after[k] - stats_before[k] for k in ("scatter_fallbacks", "lookback_fallbacks", "slot_overflows", "tile_overflows")}
     # every rank's own figures (skew between ranks, and which device each one ran on), gathered before the MAX
     per_rank = group.gather_objects({"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(local),
                                      "device_index": local, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
@@ -449,17 +447,17 @@ def main():
             if stage == "pack":
                 if args.depth16:
                     return "k_pack"
-                return "k_pack" if os.environ.get("FELICS_TWO_PASS") else "k_pack_g"
-            if stage == "offsets":
-                return "k_tile_offsets"
+                return "k_pack" if os.environ.get("FELICS_TWO_PASS") else "k_pack_t"
+            if stage == "offsets" and not args.depth16:
+                return "k_enum"
             if stage == "spine":
-                return "k_spine2"
+                return "k_spine3"
             if stage == "zero":
                 return "k_finish_sizes+k_join_edges"
             if stage == "assign" and not args.depth16:
-                return "k_assign_serial"
+                return "k_assign3"
             if stage == "scatter" and not args.depth16:
-                return scatter_kernel
+                return "k_front"
             return "k_" + stage
 
         if dom and stage_ms[dom] > 0:
@@ -548,9 +546,9 @@ def main():
             "config": {"workload": "batch of %d synthetic %s %dx%d %d-bit %s frames per GPU, resident in HBM"
                                    % (F, "S1-RGB" if args.rgb else args.kind, W, H, 16 if args.depth16 else 8,
                                       "RGB" if args.rgb else "grayscale"),
-                       "content": {"S1": "S1 natural-like synthetic (BASELINE.md section 2): smooth ramps + 3 bits of noise, ~3.6 bits per pixel; "
-                                         "the figure holds for this content only -- S2 noise frames take 3.5x the time per step, "
-                                         "natural-like frames (texture of varying strength, sharp edges) 1.1x (profiles/r03/content_sensitivity.txt)",
+                       "content": {"S1": "S1 natural-like synthetic (BASELINE.md section 2): smooth ramps + 3 bits of noise; the figure holds for "
+                                         "this content only (bits_per_pixel under `parity`); other contents, measured per round: "
+                                         "profiles/r05/content_sensitivity.txt",
                                    "S2": "S2 uniform noise (worst case)", "S3": "S3 flat (best case)"}[args.kind],
                        "baseline_config": args.config, "frames_per_gpu": F, "width": W, "height": H, "channels": channels,
                        "sharding": "frames split across ranks, no collective"},
@@ -565,6 +563,7 @@ def main():
                          "submission": "blocking calls" if args.synchronous else "%d batches in flight (submit ahead, wait in order)" % depth_q,
                          "ms_per_step_blocking_calls": None if sync_ms is None else round(sync_ms, 3),
                          "host_ms_per_submit": round(host_submit_s / steps * 1e3, 3),
+                         "batches_redone_in_timed_steps": redone,
                          "note": "the stages follow each other slice by slice on HIP streams of their own; launches overlap, so the sums exceed ms_per_step"},
             "per_rank": per_rank,
             "parity": {"frames_byte_compared_with_oracle": checked, "streams_digest_checked_after_timed_steps": F,

@@ -61,7 +61,8 @@ class _CHeader(C.Structure):
 
 class _CStats(C.Structure):
     _fields_ = [("submissions", C.c_uint64), ("ticket_retries", C.c_uint64), ("slot_overflows", C.c_uint64), ("lookback_fallbacks", C.c_uint64),
-                ("two_pass", C.c_int), ("failed", C.c_int), ("scatter_fallbacks", C.c_uint64), ("sorted_event_sorts", C.c_uint64)]
+                ("two_pass", C.c_int), ("failed", C.c_int), ("scatter_fallbacks", C.c_uint64), ("sorted_event_sorts", C.c_uint64),
+                ("tile_overflows", C.c_uint64)]
 
 
 class Header:  # format.rs:44-49

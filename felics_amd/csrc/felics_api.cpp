@@ -27,10 +27,6 @@ const char *kStageNames[ST_COUNT] = {"planes", "hist", "offsets", "scatter", "sp
                                      "wide_keys", "wide_sort", "wide_chains"};
 static_assert(ST_COUNT <= FELICS_MAX_STAGES, "felics.h promises at most FELICS_MAX_STAGES stages");
 
-// felics_ctx::scatter_mode: the ballot-ranked event sort only for queued submissions behind a batch that compressed below 3.6 bits
-// per sample (profiles/r04/scatter_sweep.txt: where the two kernels' step times cross in the queue; in blocking calls the
-// LDS-sorted kernel is at least as fast at every content measured)
-constexpr uint32_t SCATTER_BALLOT_BELOW_CENTIBITS_QUEUED = 360;
 constexpr int SLICES = 12;              // at most; a submission uses lane.nslices of them
 constexpr int EV_PAIRS = SLICES + 2;     // launches of one stage per sub-batch that can be timed
 constexpr int MAX_LANES = 4;            // upper bound of the submissions in flight (felics_submit_batch_device), each with streams and workspace of its own
@@ -63,8 +59,11 @@ struct Lane {
     hipEvent_t span_begin = nullptr, span_end = nullptr;  // profiling: in front of the sub-batch's first kernel / behind its last byte
     uint64_t *h_sizes = nullptr;      // pinned: image_bytes[n] followed by image_off[n + 1]
     size_t h_sizes_cap = 0;
-    DevBuf planes, counts, chain_len, chain_base, chain_prog, scalars, sorted_e, pix_of, k_map, k_sorted, block_state, group_bits,
-        tile_bits, tile_bitoff, plane_sums, image_bytes, image_off, partial, block_tag, status, edge_first, edge_last, pscratch;
+    // 8-bit samples, tile-local layout (felics_kernels.h): ev / pix_of / k_sorted = the tiles' slots (event value, pixel, k), counts = the
+    // run table, tile_slots, desc / block_state = the records of the chains in chain order (place + events, start state), partial =
+    // the chains' record ranges per slice, chain_prog = the chains' running state
+    DevBuf planes, counts, chain_prog, scalars, evs, pix_of, k_map, k_sorted, block_state, group_bits, tile_slots, desc,
+        tile_bits, tile_bitoff, plane_sums, image_bytes, image_off, partial, status, edge_first, edge_last, pscratch;
     DevBuf wrecs[2], wtile_cnt, wmeta, whist, wdigtot, heads, wlong;  // 16-bit samples: event records (sort double buffer), tile counts, plane ranges, digit histograms, chain heads
     uint32_t epoch = 0;               // sub-batches this lane has run: block tags are (epoch, slice)
     // the submission in flight on this lane (felics_submit_batch_device .. felics_wait_batch)
@@ -81,6 +80,8 @@ struct Lane {
     int r_rc = 0;
     // the sub-batch in flight
     int nslices = SLICES;             // slices its tiles are cut into (see felics_ctx::slices_*)
+    bool m_tickets = false;           // the sub-batch's pack kernels took their tiles by ticket (what a look-back failure escalates from)
+    bool m_fused = false;             // ... and were the single-pass kernels at all
     bool queued = false;              // this sub-batch came through felics_submit_batch_device (other submissions share the GPU with it)
     Geometry g;
     size_t first_image = 0;
@@ -110,16 +111,14 @@ struct felics_ctx {
     bool serial = false;        // FELICS_SERIAL=1 (profiling tools: every kernel alone): all stages of a lane on one stream
     bool test_timeout = false;  // FELICS_TEST_TIMEOUT=1: every wait for the GPU reports a time-out (tests of the failed state)
     bool test_lookback = false; // FELICS_TEST_LOOKBACK_FAIL=1: pretend the first single-pass submission gave up (tests)
-    // Which event sort (felics_kernels.hip, scatter).  k_scatter (a tile's events sorted in LDS, written run by run) is the
-    // default: 64 4K frames per step, noise 4.0 against 8.1 ms of k_scatter_ballot (64 events at a time straight to the chains),
-    // the headline's synthetic frames 2.8 against 2.8, blocking calls 3.55-3.7 against 3.7-3.85.  Where the events of a batch of 64
-    // crowd into three or four contexts (a smooth surface with little noise: below 3.6 bits per pixel) its LDS atomics serialise
-    // and the ballot kernel is 13-25 % faster in the queue (profiles/r04/scatter_sweep.txt): a context uses it for a queued
-    // submission when the previous batch compressed below that (bits per sample is all the host knows about content before a
-    // batch is queued).  Both produce the same bytes.  FELICS_SCATTER=sorted / ballot pins one.
-    enum ScatterMode { SCATTER_AUTO, SCATTER_SORTED, SCATTER_BALLOT } scatter_mode = SCATTER_AUTO;
-    uint32_t last_centibits = 0;     // bits per sample x 100 of the last batch whose sizes were read (0: none yet)
-    bool scatter_ballot = false;     // k_scatter's order check failed once: k_scatter_ballot from then on, whatever the mode
+    // The front kernel ranks a tile's events with returning LDS atomics and CHECKS the order it produced (felics_kernels.hip,
+    // k_front); a context whose check fails once ranks with ballots from then on (FELICS_SCATTER=ballot starts that way: tests).
+    bool scatter_ballot = false;
+    // Slots per tile of the tile-local layout: the default covers anything but adversarial content; a tile that needs more
+    // raises TL_FLAG_OVERFLOW, the batch is redone with the worst case and the context keeps to it (FELICS_TEST_TILE_CAP=1
+    // starts with a cap so small that the first batch overflows: tests).
+    bool cap_max = false;
+    bool test_tile_cap = false;
     bool test_scatter_order = false; // FELICS_TEST_SCATTER_ORDER=1: k_scatter reports a violation whatever it produced (tests)
     bool poison = false;        // FELICS_POISON=1: overwrite the workspace before every sub-batch (tests)
     bool trace = false;         // FELICS_TRACE=1: synchronise and report after every stage (debugging)
@@ -275,14 +274,14 @@ void header_bytes(uint8_t *o, uint32_t w, uint32_t h, int color, int depth) {
     }
 }
 
-// Everything one sub-batch needs, queued without waiting for the host:
-//   front stream : hist, offsets, scatter slice by slice
-//   spine stream : one spine launch behind every scatter slice
-//   tail stream  : behind every spine launch the k of the events it made servable, the code lengths
-//                  and bit offsets of that slice's tiles and -- when every stream has a fixed slot in
-//                  the output and a plane's offset in its stream is known up front (gray) -- the
-//                  packed bits of those tiles.  RGB packs after the last slice (the offset of planes
-//                  1 and 2 needs the size of the planes before them).
+// Everything one sub-batch of 8-bit frames needs, queued without waiting for the host (tile-local layout, felics_kernels.h):
+//   front stream : the front kernel (classify + sort a tile's events, once) slice by slice
+//   spine stream : behind every front slice the records of its chains (k_enum) and the spine launch that walks them
+//   k stream     : behind every spine launch the k of the slice's events (k_assign3)
+//   tail stream  : behind every k launch -- when every stream has a fixed slot in the output -- the packed bits of that
+//                  slice's tiles (k_pack_t: code lengths, tile offsets by look-back, packing in one kernel); RGB planes 1, 2
+//                  go to scratch slots and are moved behind plane 0 at the end (the offset of planes 1 and 2 needs the size
+//                  of the planes before them).
 // The stream sizes are copied to the lane's pinned buffer and `sized` is recorded behind them.
 // slot_stride == 0: no packing here (the caller places the streams exactly once it has the sizes).
 template <typename T, typename ET>
@@ -290,26 +289,27 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     const Geometry &g = l.g;
     const int ns = l.nslices;
     const size_t nsamples = (size_t)g.nplanes * g.npix;
-    const size_t slots = (size_t)max_event_slots(g);
     int rc = 0;
-    // Fixed slots: code lengths, tile offsets and packing in one kernel per slice (k_pack_g; one such kernel at a time unless the
+    // Fixed slots: code lengths, tile offsets and packing in one kernel per slice (k_pack_t; one such kernel at a time unless the
     // tiles are handed out by ticket: the tiles of two of them waiting for each other's queued predecessors could hold all
-    // workgroup slots, so the lanes share the tail stream).  It puts planes 1, 2 of an RGB image into scratch slots of their
-    // own and moves them behind plane 0 at the end.  Otherwise (exact placement, FELICS_TWO_PASS, after a look-back gave up
-    // twice): k to a byte per pixel once every chain is replayed, then the lengths / bit scan / pack kernels over all tiles.
+    // workgroup slots, so the lanes share the tail stream).  Otherwise (exact placement, FELICS_TWO_PASS, after a look-back gave
+    // up twice): k to a byte per pixel once every chain is replayed, then the lengths / bit scan / pack kernels over all tiles.
     const bool fused = slot_stride != 0 && !ctx->two_pass;
-    if ((rc = reserve(ctx, l.counts, (size_t)g.nplanes * g.sort_tiles * g.nctx * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, l.chain_len, (size_t)g.nplanes * g.nctx * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, l.chain_base, (size_t)g.nplanes * g.nctx * 4)) != 0) return rc;
-    if ((rc = reserve(ctx, l.chain_prog, (size_t)g.nplanes * g.nctx * 32)) != 0) return rc;
-    if ((rc = reserve(ctx, l.scalars, 64 + 4 * (SLICES + 2))) != 0) return rc;
-    if ((rc = reserve(ctx, l.sorted_e, slots * sizeof(ET) + SORTED_PAD)) != 0) return rc;
-    if ((rc = reserve(ctx, l.pix_of, slots * 4)) != 0) return rc;
-    if (!fused && (rc = reserve(ctx, l.k_map, nsamples + STAGE_PAD)) != 0) return rc;
+    const uint32_t cap = ctx->cap_max ? tile_cap_max(g.nctx, g.npix) : ctx->test_tile_cap ? std::min(4u * REC, tile_cap_max(g.nctx, g.npix)) : tile_cap_default(g.nctx, g.npix);
+    const size_t ptiles = (size_t)g.nplanes * g.sort_tiles;
+    const size_t slots = ptiles * cap, recs = slots / REC;
+    const size_t nchains = (size_t)g.nplanes * g.nctx;
+    if ((rc = reserve(ctx, l.evs, slots * sizeof(ET) + STAGE_PAD)) != 0) return rc;
+    if ((rc = reserve(ctx, l.pix_of, slots * 2 + STAGE_PAD)) != 0) return rc;
     if ((rc = reserve(ctx, l.k_sorted, slots + STAGE_PAD)) != 0) return rc;
-    if ((rc = reserve(ctx, l.block_state, (size_t)max_event_blocks(g) * 32)) != 0) return rc;
-    if ((rc = reserve(ctx, l.partial, (size_t)SLICES * g.nplanes * g.nctx * 8)) != 0) return rc;
-    if ((rc = reserve_zeroed(ctx, l.block_tag, (size_t)max_event_blocks(g) * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.counts, ptiles * g.nctx * 4)) != 0) return rc;        // the run table
+    if ((rc = reserve(ctx, l.tile_slots, ptiles * 4)) != 0) return rc;
+    if ((rc = reserve(ctx, l.desc, recs * 8 + 64)) != 0) return rc;
+    if ((rc = reserve(ctx, l.block_state, recs * 16 + 64)) != 0) return rc;         // state16
+    if ((rc = reserve(ctx, l.partial, (size_t)SLICES * nchains * 8)) != 0) return rc;  // chain_seg per slice
+    if ((rc = reserve(ctx, l.chain_prog, nchains * 32)) != 0) return rc;            // chain_state
+    if ((rc = reserve(ctx, l.scalars, 64 + 4 * (SLICES + 2) + 4 * SLICES)) != 0) return rc;
+    if (!fused && (rc = reserve(ctx, l.k_map, nsamples + STAGE_PAD)) != 0) return rc;
     if (!fused && (rc = reserve(ctx, l.group_bits, (size_t)g.nplanes * g.pack_tiles * PACK_THREADS * 2)) != 0) return rc;
     if ((rc = reserve(ctx, l.tile_bits, (size_t)g.nplanes * g.pack_tiles * 4)) != 0) return rc;
     if ((rc = reserve(ctx, l.tile_bitoff, (size_t)g.nplanes * g.pack_tiles * 8)) != 0) return rc;
@@ -329,18 +329,11 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     hipStream_t s = l.stream, f = l.front, ks = l.kstream, tl = l.tail;
     if (ctx->serial) f = ks = tl = s;  // FELICS_SERIAL (profiling: every kernel alone): one stream, same order of launches
     const T *d_planes = (const T *)l.d_planes;
-    auto *counts = (uint32_t *)l.counts.p;
-    auto *chain_len = (uint32_t *)l.chain_len.p;
-    auto *chain_base = (uint32_t *)l.chain_base.p;
-    auto *chain_prog = (uint32_t *)l.chain_prog.p;
+    auto *chain_state = (uint32_t *)l.chain_prog.p;
     auto *plane_carry = (uint64_t *)l.plane_sums.p;
     auto *plane_base = plane_carry + g.nplanes;
-    // tags of other sub-batches never match this epoch (the lane's tags are cleared when the counter wraps)
-    if (++l.epoch >= 0x03FFFFFFu) {
-        HIP_TRY(ctx, hipMemset(l.block_tag.p, 0, l.block_tag.cap));
-        l.epoch = 1;
-    }
-    if ((l.epoch & 0x3FFFFu) == 0) HIP_TRY(ctx, hipMemset(l.status.p, 0, l.status.cap));  // look-back tags: 18 epoch bits
+    if (++l.epoch >= 0x03FFFFFFu) l.epoch = 1;
+    if ((l.epoch & 0x3FFFFu) == 0) HIP_TRY(ctx, hipMemsetAsync(l.status.p, 0, l.status.cap, f));  // look-back tags: 18 epoch bits
     const uint32_t epoch = l.epoch;
     PackTarget target{d_out, slot_stride, nullptr, 0};
     if (fused && g.planes_per_image > 1) {
@@ -349,62 +342,61 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         target.scratch = (uint8_t *)l.pscratch.p;
     }
     uint32_t *d_error = (uint32_t *)l.scalars.p + 8;  // look-back watchdog of the single-pass pack
-    uint32_t *d_order = (uint32_t *)l.scalars.p + 9;  // k_scatter's order check (read back together with d_error)
+    uint32_t *d_flags = (uint32_t *)l.scalars.p + 9;  // TL_FLAG_*: the front kernel's order check and tile overflow, the spine's self-check (read back together with d_error)
     uint32_t *d_tickets = (uint32_t *)l.scalars.p + 16;  // one per pack launch of this sub-batch: tiles are handed out in order
+    uint32_t *d_nrec = (uint32_t *)l.scalars.p + 16 + SLICES + 2;  // records per slice
+    const TileLocal<ET> tloc{(ET *)l.evs.p, (uint16_t *)l.pix_of.p, (uint8_t *)l.k_sorted.p, (uint32_t *)l.counts.p, (uint32_t *)l.tile_slots.p, cap};
+    l.m_tickets = ctx->pack_tickets;
+    l.m_fused = fused;
 
     uint32_t bounds[SLICES + 1];  // slice boundaries in sort tiles (= pack tiles)
     for (int q = 0; q <= ns; q++) bounds[q] = (uint32_t)((uint64_t)g.sort_tiles * q / ns);
+    // the records of slice q live in their own region of desc / state16: as many as its tiles can hold
+    auto slice_of = [&](int q) {
+        const size_t r0 = (size_t)bounds[q] * g.nplanes * (cap / REC);
+        return ChainSlice{(uint2 *)l.desc.p + r0, (uint2 *)l.partial.p + (size_t)q * nchains, d_nrec + q, (uint4 *)l.block_state.p + r0};
+    };
     // ---- front stream
     if (ctx->poison) {  // FELICS_POISON: every intermediate buffer starts as garbage, as on a fresh context
-        DevBuf *bufs[] = {&l.counts, &l.chain_len, &l.chain_base, &l.sorted_e, &l.pix_of, &l.k_map, &l.k_sorted, &l.block_state,
+        DevBuf *bufs[] = {&l.evs, &l.pix_of, &l.k_sorted, &l.counts, &l.tile_slots, &l.desc, &l.block_state, &l.partial, &l.k_map,
                           &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.edge_first, &l.edge_last, &l.pscratch};
         for (DevBuf *b : bufs)
             if (b->p) HIP_TRY(ctx, hipMemsetAsync(b->p, 0xA5, b->cap, f));
     }
-    {
-        StageTimer t(ctx, l, ST_HIST, f, true);
-        launch_hist<T>(f, d_planes, counts, g);
-    }
-    {
-        StageTimer t(ctx, l, ST_OFFSETS, f);
-        launch_offsets(f, counts, chain_len, chain_base, (uint32_t *)l.scalars.p, g);
-        launch_zero_padding<ET>(f, (ET *)l.sorted_e.p, fused ? nullptr : (uint32_t *)l.pix_of.p, chain_base, chain_len, g);
-        HIP_TRY(ctx, hipMemsetAsync(chain_prog, 0, (size_t)g.nplanes * g.nctx * 32, f));
-        HIP_TRY(ctx, hipMemsetAsync(l.partial.p, 0, (size_t)ns * g.nplanes * g.nctx * 8, f));
-    }
-    HIP_TRY(ctx, hipMemsetAsync(d_order, 0, 4, f));
-    const bool by_ballot = ctx->scatter_ballot || ctx->scatter_mode == felics_ctx::SCATTER_BALLOT ||
-                           (ctx->scatter_mode == felics_ctx::SCATTER_AUTO && l.queued && ctx->last_centibits != 0 &&
-                            ctx->last_centibits < SCATTER_BALLOT_BELOW_CENTIBITS_QUEUED);
-    if (!by_ballot) ctx->stats.sorted_event_sorts++;
+    HIP_TRY(ctx, hipMemsetAsync(chain_state, 0, nchains * 32, f));
+    HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, 4, f));
+    HIP_TRY(ctx, hipMemsetAsync(d_nrec, 0, 4 * SLICES, f));
+    // (FELICS_TEST_SCATTER_ORDER: the atomically ranked kernel reports a violation whatever it produced; the ballot-ranked form is
+    // the remedy and is checked for real)
+    const uint32_t front_mode = ctx->scatter_ballot ? FRONT_SAFE_RANK : ctx->test_scatter_order ? FRONT_TEST_VIOLATION : 0u;
+    if (!ctx->scatter_ballot) ctx->stats.sorted_event_sorts++;
     for (int q = 0; q < ns; q++) {
         if (bounds[q + 1] != bounds[q]) {
             StageTimer t(ctx, l, ST_SCATTER, f, true);
-            // (the single-pass pack knows its tile: pix_of then holds 16-bit offsets into the sort tile)
-            launch_scatter<T, ET>(f, d_planes, counts, chain_base, (ET *)l.sorted_e.p, (uint32_t *)l.pix_of.p, fused, g,
-                                  bounds[q], bounds[q + 1], d_order, by_ballot, ctx->test_scatter_order);
+            launch_front<T, ET>(f, d_planes, tloc, g, bounds[q], bounds[q + 1], d_flags, front_mode);
         }
         HIP_TRY(ctx, hipEventRecord(l.slice_done[q], f));
     }
-    // ---- spine stream
+    // ---- spine stream: the slice's records in chain order, then the walk along every chain
     for (int q = 0; q < ns; q++) {
         HIP_TRY(ctx, hipStreamWaitEvent(s, l.slice_done[q], 0));
-        if (bounds[q + 1] != bounds[q] || q + 1 == ns) {
+        if (bounds[q + 1] != bounds[q]) {
+            const ChainSlice cs = slice_of(q);
+            {
+                StageTimer t(ctx, l, ST_OFFSETS, s, true);
+                launch_enum(s, tloc.runtab, cs, g, bounds[q], bounds[q + 1], cap);
+            }
             StageTimer t(ctx, l, ST_SPINE, s, true);
-            launch_spine<ET>(s, (const ET *)l.sorted_e.p, (uint32_t *)l.block_state.p, chain_base, chain_len, counts,
-                             bounds[q + 1], chain_prog, (uint32_t *)l.block_tag.p, (uint32_t *)l.partial.p, epoch,
-                             (uint32_t)q + 1, g);
+            launch_spine3<ET>(s, tloc.ev, cs, chain_state, d_flags, g);
         }
         HIP_TRY(ctx, hipEventRecord(l.spine_done[q], s));
     }
-    // ---- k stream: behind every spine launch, k of the events it published, in chain order
+    // ---- k stream: behind every spine launch, k of the slice's events
     for (int q = 0; q < ns; q++) {
         HIP_TRY(ctx, hipStreamWaitEvent(ks, l.spine_done[q], 0));
-        if (bounds[q + 1] != bounds[q] || q + 1 == ns) {
+        if (bounds[q + 1] != bounds[q]) {
             StageTimer t(ctx, l, ST_ASSIGN, ks, true);
-            launch_assign_serial<ET>(ks, (const ET *)l.sorted_e.p, (uint8_t *)l.k_sorted.p, (const uint32_t *)l.block_state.p,
-                                     (const uint32_t *)l.scalars.p, (const uint32_t *)l.block_tag.p,
-                                     (const uint32_t *)l.partial.p, epoch, (uint32_t)q + 1, g);
+            launch_assign3<ET>(ks, tloc.ev, slice_of(q), tloc.kq, g);
         }
         HIP_TRY(ctx, hipEventRecord(l.assign_done[q], ks));
     }
@@ -418,10 +410,9 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
             HIP_TRY(ctx, hipStreamWaitEvent(tl, l.assign_done[q], 0));
             if (bounds[q + 1] == bounds[q]) continue;
             StageTimer t(ctx, l, ST_PACK, tl, true);
-            launch_pack_g<T>(tl, d_planes, (const uint8_t *)l.k_sorted.p, (const uint32_t *)l.pix_of.p, counts, chain_base, chain_len,
-                             (uint64_t *)l.status.p, (uint64_t *)l.tile_bitoff.p, (uint32_t *)l.tile_bits.p, plane_carry,
-                             (uint32_t *)l.edge_first.p, (uint32_t *)l.edge_last.p, d_error, target, g, bounds[q], bounds[q + 1], epoch,
-                             ctx->pack_tickets ? d_tickets + q : nullptr);
+            launch_pack_t<T>(tl, d_planes, tloc.kq, tloc.pix, tloc.tile_slots, cap, (uint64_t *)l.status.p, (uint64_t *)l.tile_bitoff.p,
+                             (uint32_t *)l.tile_bits.p, plane_carry, (uint32_t *)l.edge_first.p, (uint32_t *)l.edge_last.p, d_error, target, g,
+                             bounds[q], bounds[q + 1], epoch, ctx->pack_tickets ? d_tickets + q : nullptr);
         }
         StageTimer t(ctx, l, ST_ZERO, tl);
         launch_finish_sizes(tl, plane_carry, plane_base, (uint64_t *)l.image_bytes.p, g);
@@ -432,8 +423,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         HIP_TRY(ctx, hipStreamWaitEvent(tl, l.assign_done[ns - 1], 0));
         {
             StageTimer t(ctx, l, ST_ASSIGN, tl, true);
-            launch_k_to_pixels(tl, (const uint8_t *)l.k_sorted.p, (const uint32_t *)l.pix_of.p, (uint8_t *)l.k_map.p,
-                               (const uint32_t *)l.scalars.p, g);
+            launch_k_to_pixels_tl(tl, tloc.kq, tloc.pix, tloc.tile_slots, cap, (uint8_t *)l.k_map.p, g);
         }
         {
             StageTimer t(ctx, l, ST_LENGTHS, tl, true);
@@ -460,7 +450,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(l.h_sizes, l.image_bytes.p, (size_t)g.nimages * 8, hipMemcpyDeviceToHost, tl));
     l.h_sizes[g.nimages] = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&l.h_sizes[g.nimages], d_error, 8, hipMemcpyDeviceToHost, tl));  // d_error | d_order << 32
+    HIP_TRY(ctx, hipMemcpyAsync(&l.h_sizes[g.nimages], d_error, 8, hipMemcpyDeviceToHost, tl));  // d_error | d_flags << 32
     HIP_TRY(ctx, hipEventRecord(l.sized, tl));
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(l.span_end, tl));
     return FELICS_OK;
@@ -609,7 +599,10 @@ size_t max_images_per_pass(uint64_t npix, uint32_t planes, int depth) {
         constexpr uint64_t WIDE_MAX_PLANES = 1u << 16;
         return (size_t)std::max<uint64_t>(1, std::min<uint64_t>(0x40000000ull / per_image, WIDE_MAX_PLANES / planes));
     }
-    return (size_t)std::max<uint64_t>(1, 0xE0000000ull / (per_image + 64ull * planes * NCTX));
+    // the records of a pass are numbered with 32 bits: tiles x records per tile (worst case)
+    const uint64_t tiles = (npix + SORT_TILE - 1) / SORT_TILE;
+    const uint64_t rec_per_image = tiles * planes * (tile_cap_max(NCTX, (uint32_t)std::min<uint64_t>(npix, SORT_TILE)) / REC);
+    return (size_t)std::max<uint64_t>(1, std::min(0xE0000000ull / per_image, 0xE0000000ull / rec_per_image));
 }
 
 // Queues one sub-batch (cnt frames starting at frame `first` of d_pixels) on a lane: geometry, colour
@@ -659,24 +652,27 @@ int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const v
 struct SlotOutcome {
     bool lookback_failed = false;  // a tile of the single-pass pack gave up waiting for the tiles before it
     bool overflow = false;         // a stream outgrew its slot, or an RGB plane its scratch slot
-    bool order_violation = false;  // k_scatter's check of its own output failed: nothing of this sub-batch is to be used
-    bool redo() const { return lookback_failed || order_violation; }
+    bool order_violation = false;  // the front kernel's check of its own output failed: nothing of this sub-batch is to be used
+    bool tile_overflow = false;    // a tile's events did not fit its slots (tile_cap_default): nothing of this sub-batch is to be used
+    bool spine_error = false;      // the spine's search lost its invariant (never seen): an internal error, reported as such
+    bool redo() const { return lookback_failed || order_violation || tile_overflow; }
 };
 
 SlotOutcome read_sizes(felics_ctx *ctx, Lane &l, bool wide, uint64_t slot, uint64_t *offsets, uint64_t *lens) {
     SlotOutcome o;
-    if (!wide && ((l.h_sizes[l.g.nimages] & 1u) != 0 || (ctx->test_lookback && !ctx->two_pass))) o.lookback_failed = true;
-    if (!wide && (l.h_sizes[l.g.nimages] & 2u) != 0) o.overflow = true;
-    if (!wide && (l.h_sizes[l.g.nimages] >> 32) != 0) o.order_violation = true;
-    uint64_t bytes = 0;
+    const uint32_t err = (uint32_t)l.h_sizes[l.g.nimages], flags = (uint32_t)(l.h_sizes[l.g.nimages] >> 32);
+    if (!wide) {
+        if ((err & 1u) != 0 || (ctx->test_lookback && l.m_fused)) o.lookback_failed = true;
+        if ((err & 2u) != 0) o.overflow = true;
+        if ((flags & TL_FLAG_ORDER) != 0) o.order_violation = true;
+        if ((flags & TL_FLAG_OVERFLOW) != 0) o.tile_overflow = true;
+        if ((flags & TL_FLAG_SPINE) != 0) o.spine_error = true;
+    }
     for (size_t i = 0; i < l.g.nimages; i++) {
         lens[l.first_image + i] = l.h_sizes[i];
-        bytes += l.h_sizes[i];
         offsets[l.first_image + i] = (uint64_t)(l.first_image + i) * slot;
         if (slot != 0 && l.h_sizes[i] > slot) o.overflow = true;
     }
-    if (!wide && !o.redo() && l.g.nplanes != 0 && l.g.npix != 0)
-        ctx->last_centibits = (uint32_t)std::min<uint64_t>(bytes * 800u / ((uint64_t)l.g.nplanes * l.g.npix), 100000u);
     return o;
 }
 
@@ -685,11 +681,11 @@ SlotOutcome read_sizes(felics_ctx *ctx, Lane &l, bool wide, uint64_t slot, uint6
 // and the other lane's kernels share them), so the first remedy is the ticket counter -- same kernel, a tile then only waits
 // for workgroups that are running.  If a ticketed pack gives up as well, something else holds the GPU for a second at a time:
 // the context packs with the two-pass kernels from then on.
-void note_lookback_failure(felics_ctx *ctx) {
+void note_lookback_failure(felics_ctx *ctx, const Lane &l) {
     ctx->stats.lookback_fallbacks++;
-    if (!ctx->pack_tickets) {
+    if (!l.m_tickets) {  // (what the failed sub-batch itself ran with: two queued submissions that fail together both get here)
+        if (!ctx->pack_tickets) ctx->stats.ticket_retries++;
         ctx->pack_tickets = true;
-        ctx->stats.ticket_retries++;
         ctx->err = "a tile gave up waiting for its predecessors: this context now hands its pack tiles out by ticket";
     } else {
         ctx->two_pass = true;
@@ -698,13 +694,26 @@ void note_lookback_failure(felics_ctx *ctx) {
     }
 }
 
-// k_scatter ranks a batch of events with one returning LDS atomic and relies on the lanes that name one address being served in
+// k_front ranks a batch of events with one returning LDS atomic and relies on the lanes that name one address being served in
 // lane order -- which this hardware does (profiles/tools/micro/lds_atomic_order.hip) and no document promises; so the kernel
-// checks the order of what it wrote, and a context whose check fails once uses the ballot-ranked kernel from then on.
+// checks the order of what it wrote, and a context whose check fails once ranks with ballots from then on.
 void note_scatter_order_violation(felics_ctx *ctx) {
     ctx->stats.scatter_fallbacks++;
     ctx->scatter_ballot = true;
-    ctx->err = "k_scatter's order check failed: this context now ranks events with ballots (k_scatter_ballot)";
+    ctx->err = "the front kernel's order check failed: this context now ranks events with ballots";
+}
+
+// A tile's events did not fit the slots a tile gets by default: the worst case from now on (more memory, same kernels).
+void note_tile_overflow(felics_ctx *ctx) {
+    ctx->stats.tile_overflows++;
+    ctx->cap_max = true;
+    ctx->test_tile_cap = false;
+    ctx->err = "a tile's events outgrew its slots: this context now sizes its tiles for the worst case";
+}
+
+int spine_failure(felics_ctx *ctx) {
+    ctx->err = "internal error: the spine's halving search lost its invariant";
+    return FELICS_E_HIP;
 }
 
 // Encode `n` same-shape frames resident in device memory into d_out (device), on one lane, and wait.
@@ -766,7 +775,10 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
     }
     if (start_exact) slot = 0;
 
-    for (int attempt = 0; attempt < 5; attempt++) {  // (at most: ballot scatter, tickets, two-pass, exact placement, and the run that succeeds)
+    // (at most: ranks from ballots, worst-case tiles, tickets, two-pass, exact placement, and the run that succeeds; a loop that
+    // runs out without one is reported, not passed off as a result)
+    bool complete = false;
+    for (int attempt = 0; attempt < 7 && !complete; attempt++) {
         size_t done = 0;
         uint64_t out_base = 0;  // exact placement: where the next pass's streams start
         SlotOutcome outcome;
@@ -780,7 +792,11 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
             }
             if ((rc = wait_event(ctx, l.sized, "stream sizes")) != 0) return rc;
             outcome = read_sizes(ctx, l, wide, slot, offsets, lens);
-            if (slot == 0 && !outcome.order_violation) {
+            if (outcome.spine_error) {
+                (void)sync_lane(ctx, l);
+                return spine_failure(ctx);
+            }
+            if (slot == 0 && !outcome.redo()) {
                 // exact placement of this pass: back to back, 16-byte aligned, in image order
                 uint64_t need = out_base;
                 for (size_t i = done; i < first; i++) {
@@ -817,13 +833,22 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
             if ((rc = sync_lane(ctx, l)) != 0) return rc;
             if (outcome.order_violation)
                 note_scatter_order_violation(ctx);
+            else if (outcome.tile_overflow)
+                note_tile_overflow(ctx);
             else
-                note_lookback_failure(ctx);
+                note_lookback_failure(ctx, l);
             continue;
         }
-        if (!outcome.overflow) break;
+        if (!outcome.overflow) {
+            complete = true;
+            break;
+        }
         ctx->stats.slot_overflows++;
         slot = 0;  // a stream outgrew its slot: do the batch again with exact placement
+    }
+    if (!complete) {
+        ctx->err = "internal error: the batch was redone with every remedy and still did not complete";
+        return FELICS_E_HIP;
     }
     collect_timing(ctx, l);
     if (used_out) *used_out = d_out;
@@ -861,8 +886,8 @@ int felics_ctx_create(int device, felics_ctx **out) {
     ctx->poison = getenv("FELICS_POISON") != nullptr;
     ctx->two_pass = getenv("FELICS_TWO_PASS") != nullptr;
     ctx->test_lookback = getenv("FELICS_TEST_LOOKBACK_FAIL") != nullptr;
-    if (const char *e = getenv("FELICS_SCATTER"))
-        ctx->scatter_mode = !strcmp(e, "sorted") ? felics_ctx::SCATTER_SORTED : !strcmp(e, "ballot") ? felics_ctx::SCATTER_BALLOT : felics_ctx::SCATTER_AUTO;
+    if (const char *e = getenv("FELICS_SCATTER")) ctx->scatter_ballot = !strcmp(e, "ballot");
+    ctx->test_tile_cap = getenv("FELICS_TEST_TILE_CAP") != nullptr;
     ctx->test_scatter_order = getenv("FELICS_TEST_SCATTER_ORDER") != nullptr;
     ctx->pack_tickets = ctx->own_tails = getenv("FELICS_OWN_TAILS") != nullptr;
     ctx->serial = getenv("FELICS_SERIAL") != nullptr;
@@ -925,9 +950,9 @@ void felics_ctx_destroy(felics_ctx *ctx) {
     for (Lane &l : ctx->lanes)
         if (l.tail) (void)hipStreamSynchronize(l.tail);
     for (Lane &l : ctx->lanes) {
-        DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_len, &l.chain_base, &l.chain_prog, &l.scalars, &l.sorted_e, &l.pix_of, &l.k_map, &l.k_sorted,
+        DevBuf *bufs[] = {&l.planes, &l.counts, &l.chain_prog, &l.scalars, &l.evs, &l.pix_of, &l.k_map, &l.k_sorted, &l.tile_slots, &l.desc,
                           &l.block_state, &l.group_bits, &l.tile_bits, &l.tile_bitoff, &l.plane_sums, &l.image_bytes, &l.image_off,
-                          &l.partial, &l.block_tag, &l.status, &l.edge_first, &l.edge_last, &l.pscratch, &l.wrecs[0], &l.wrecs[1], &l.wtile_cnt, &l.wmeta, &l.whist, &l.wdigtot, &l.heads, &l.wlong};
+                          &l.partial, &l.status, &l.edge_first, &l.edge_last, &l.pscratch, &l.wrecs[0], &l.wrecs[1], &l.wtile_cnt, &l.wmeta, &l.whist, &l.wdigtot, &l.heads, &l.wlong};
         for (DevBuf *b : bufs) release(*b);
         if (l.h_sizes) (void)hipHostFree(l.h_sizes);
         for (int i = 0; i < ST_COUNT; i++)
@@ -1042,16 +1067,19 @@ int felics_wait_batch(felics_ctx *ctx, int ticket, uint64_t *offsets, uint64_t *
     }
     int rc;
     const SlotOutcome o = read_sizes(ctx, l, l.p_depth == FELICS_DEPTH_16, l.p_slot, offsets, lens);
-    if (!o.redo() && !o.overflow) {
+    if (!o.redo() && !o.overflow && !o.spine_error) {
         collect_timing(ctx, l);
         return FELICS_OK;
     }
     // the rare cases: pack again on this lane, synchronously (two-pass kernels / exact placement)
     if ((rc = sync_lane(ctx, l)) != 0) return rc;
+    if (o.spine_error) return spine_failure(ctx);
     if (o.order_violation) {
         note_scatter_order_violation(ctx);
+    } else if (o.tile_overflow) {
+        note_tile_overflow(ctx);
     } else if (o.lookback_failed) {
-        note_lookback_failure(ctx);
+        note_lookback_failure(ctx, l);
     } else {
         ctx->stats.slot_overflows++;
     }

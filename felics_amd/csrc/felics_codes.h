@@ -37,6 +37,37 @@ __device__ __forceinline__ void packed_lengths(uint32_t e, uint32_t &l01, uint32
 }
 
 
+// The estimator's six counters as KEYS: key_k = S_k << 3 | (7 - k).  The smallest key names the smallest counter and,
+// among equal counters, the largest k (`<=` at parameter_selection.rs:79); min(S) > 1024 <=> min key >= 1025 << 3.
+struct EstKeys {
+    uint32_t k0, k1, k2, k3, k4, k5, m;  // m = the smallest key (kept up to date by set / step)
+    __device__ __forceinline__ void set(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t s4, uint32_t s5) {
+        k0 = (s0 << 3) | 7u; k1 = (s1 << 3) | 6u; k2 = (s2 << 3) | 5u;
+        k3 = (s3 << 3) | 4u; k4 = (s4 << 3) | 3u; k5 = (s5 << 3) | 2u;
+        m = min_key();
+    }
+    __device__ __forceinline__ uint32_t min_key() const { return min(min(min(k0, k1), k2), min(min(k3, k4), k5)); }
+    // one event: returns 7 - k (k = get_k before the update), then update + halving
+    __device__ __forceinline__ uint32_t step(uint32_t e) {
+        const uint32_t r = m & 7u;
+        const uint32_t e8 = e << 3;
+        k0 += e8 + 8u;
+        k1 += ((e8 >> 1) & ~7u) + 16u;
+        k2 += ((e8 >> 2) & ~7u) + 24u;
+        k3 += ((e8 >> 3) & ~7u) + 32u;
+        k4 += ((e8 >> 4) & ~7u) + 40u;
+        k5 += ((e8 >> 5) & ~7u) + 48u;
+        m = min_key();
+        if (m >= (1025u << 3)) {  // x /= 2 on every counter (parameter_selection.rs:62)
+            k0 = ((k0 >> 1) & ~7u) | 7u; k1 = ((k1 >> 1) & ~7u) | 6u; k2 = ((k2 >> 1) & ~7u) | 5u;
+            k3 = ((k3 >> 1) & ~7u) | 4u; k4 = ((k4 >> 1) & ~7u) | 3u; k5 = ((k5 >> 1) & ~7u) | 2u;
+            m = min_key();
+        }
+        return r;
+    }
+};
+
+
 // Phased-in code of v in [0, n) (phase_in_coding.rs:23-84): r = v + 2^m (mod n);
 // r < right_p -> r in m bits, else r + right_p in m + 1 bits.  n - left_p = 2^m, so no division.
 __device__ __forceinline__ void phase_in(uint32_t n, uint32_t v, uint32_t &bits, uint32_t &nbits) {

@@ -69,6 +69,62 @@ struct Geometry {
 
 void launch_rgb8_to_planes(hipStream_t s, const uint8_t *rgb, int16_t *planes, uint32_t npix, uint32_t nimg);
 
+// ------------------------------------------------------------------------------------------
+// The 8-bit pipeline in TILE-LOCAL layout (round 5).  A pixel is classified once: the front kernel sorts the events of
+// a tile (SORT_TILE pixels) by context in LDS and writes them as ONE contiguous piece at a fixed place,
+//     slot (plane * sort_tiles + tile) * cap + s,
+// contexts ascending, raster order inside a context, every context's run starting on a multiple of REC slots (the slots
+// between a run's end and the next multiple are padding: pix = 0xFFFF).  A RECORD is REC = 16 consecutive slots of one
+// run: the unit of the chain stage -- the spine leaves the estimator's state at the start of every record, the assign
+// kernel replays a record per lane -- and of the k bytes the pack kernel reads back, contiguous per tile.  No histogram
+// pass, no tile offsets, no chain bases, no global scatter: the chain of a context is the sequence of its runs over the
+// tiles, listed per slice by k_enum (record descriptors in chain order).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t REC = 16;  // events per record
+// Slots per tile.  Worst case SORT_TILE + (REC - 1) * nctx (every context one event over a multiple of REC); the default
+// covers anything but adversarial content (uniform noise: 216 runs of a 4096-pixel tile, ~4400 slots); a tile that needs
+// more raises TL_FLAG_OVERFLOW and the host redoes the batch with the worst case (felics_api.cpp).
+// (npix: pixels per plane -- a plane smaller than a tile needs less)
+inline uint32_t tile_cap_max(uint32_t nctx, uint32_t npix) {
+    const uint32_t px = std::min(npix, SORT_TILE);
+    return (px + (REC - 1) * std::min(nctx, px) + REC - 1) / REC * REC;
+}
+inline uint32_t tile_cap_default(uint32_t nctx, uint32_t npix) { return std::min(nctx == 256 ? 6144u : 8192u, tile_cap_max(nctx, npix)); }
+constexpr uint32_t TL_FLAG_ORDER = 1u, TL_FLAG_OVERFLOW = 2u, TL_FLAG_SPINE = 4u;
+constexpr uint32_t FRONT_TEST_VIOLATION = 1u, FRONT_SAFE_RANK = 2u;  // k_front's `mode` bits
+
+template <typename ET>
+struct TileLocal {
+    ET *ev;                // [slot] value to Rice-code
+    uint16_t *pix;         // [slot] the event's pixel: offset in its tile; 0xFFFF in padding slots
+    uint8_t *kq;           // [slot] k of the event (k_assign3)
+    uint32_t *runtab;      // [(plane * sort_tiles + tile) * nctx + c] = first record of the tile's run of c (in the tile) | events << 16
+    uint32_t *tile_slots;  // [plane * sort_tiles + tile] slots in use (a multiple of REC)
+    uint32_t cap;          // slots per tile
+};
+// classify + sort the tiles [tile_begin, tile_end) of every plane (compression.rs:124-145, misc.rs:6-24)
+template <typename T, typename ET>
+void launch_front(hipStream_t s, const T *planes, const TileLocal<ET> &tl, const Geometry &g, uint32_t tile_begin, uint32_t tile_end,
+                  uint32_t *flags, uint32_t mode);
+
+// The chain stage of one slice: records [0, *nrec) of the slice's region of desc / state16.
+struct ChainSlice {
+    uint2 *desc;           // [rec] {record's first slot / REC (over the whole sub-batch), events in it}: chain order
+    uint2 *chain_seg;      // [chain] {first record, records} of the chain in this slice
+    uint32_t *nrec;        // records of the slice (device counter, zeroed per sub-batch)
+    uint4 *state16;        // [rec] {S0 | S1 << 16, S2 | S3 << 16, S4 | S5 << 16, first slot / REC}: the estimator's state at the record's first event
+};
+void launch_enum(hipStream_t s, const uint32_t *runtab, const ChainSlice &cs, const Geometry &g, uint32_t tile_begin, uint32_t tile_end,
+                 uint32_t cap);
+// chain_state: 8 words per chain (zeroed per sub-batch): the state behind the chain's last event so far
+template <typename ET>
+void launch_spine3(hipStream_t s, const ET *ev, const ChainSlice &cs, uint32_t *chain_state, uint32_t *flags, const Geometry &g);
+template <typename ET>
+void launch_assign3(hipStream_t s, const ET *ev, const ChainSlice &cs, uint8_t *kq, const Geometry &g);
+// two-pass pack: k from the tiles' slots to a byte per pixel
+void launch_k_to_pixels_tl(hipStream_t s, const uint8_t *kq, const uint16_t *pix, const uint32_t *tile_slots, uint32_t cap, uint8_t *k_map,
+                           const Geometry &g);
+
 template <typename T>
 void launch_hist(hipStream_t s, const T *planes, uint32_t *counts, const Geometry &g);
 
@@ -169,6 +225,12 @@ void launch_pack_g(hipStream_t s, const T *planes, const uint8_t *k_sorted, cons
                    const uint32_t *chain_base, const uint32_t *chain_len, uint64_t *status, uint64_t *tile_bitoff,
                    uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last, uint32_t *error,
                    const PackTarget &to, const Geometry &g, uint32_t st0, uint32_t st1, uint32_t epoch, uint32_t *ticket);
+// the single-pass pack on the tile-local layout: k gathered from the tile's own slots (kq / pix / tile_slots of TileLocal)
+template <typename T>
+void launch_pack_t(hipStream_t s, const T *planes, const uint8_t *kq, const uint16_t *pix, const uint32_t *tile_slots, uint32_t cap,
+                   uint64_t *status, uint64_t *tile_bitoff, uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first,
+                   uint32_t *edge_last, uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t st0, uint32_t st1, uint32_t epoch,
+                   uint32_t *ticket);
 // two-pass pack: k from chain order (k_sorted) to a byte per pixel (k_map), all slots at once; pix_of = plane * npix + i
 void launch_k_to_pixels(hipStream_t s, const uint8_t *k_sorted, const uint32_t *pix_of, uint8_t *k_map, const uint32_t *total_slots,
                          const Geometry &g);

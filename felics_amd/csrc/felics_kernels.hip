@@ -744,6 +744,247 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 5))) __global__ __launch
 }
 
 // ------------------------------------------------------------------------------------------
+// k_front (round 5): the ONE classification of a pixel.  k_scatter's steps 1-4 as they are (classify, compact, rank with a
+// returning LDS add, layout, place into the tile's sorted order in LDS); what changes is where the sorted tile goes: not to
+// the chains (which needed every tile's counts first: a histogram pass and a scan over the tiles) but to the tile's own
+// place, slot (plane * ntiles + tile) * cap + s -- contexts ascending, every context's run starting on a multiple of REC
+// slots (felics_kernels.h: tile-local layout) -- with the run table {first record, events} per context and the slots in use.
+// The chain of a context is then the sequence of its runs over the tiles (felics_chain.hip).
+//   mode & FRONT_SAFE_RANK: ranks from ballots instead of the returning add (the context's fallback once the order check
+//   of step 5 has failed: no assumption about the LDS); mode & FRONT_TEST_VIOLATION: report a violation whatever the order.
+// ------------------------------------------------------------------------------------------
+template <typename T, typename ET>
+__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 5))) __global__ __launch_bounds__(256) void k_front(
+    const T *__restrict__ planes, ET *__restrict__ ev, uint16_t *__restrict__ pix, uint32_t *__restrict__ runtab,
+    uint32_t *__restrict__ tile_slots, uint32_t W, uint32_t npix, uint32_t ntiles, uint32_t tile_begin, uint32_t tile_end,
+    uint32_t nplanes, uint32_t cap, uint32_t *__restrict__ flags, uint32_t mode) {
+    constexpr uint32_t NC = nctx_of<T>();
+    constexpr uint32_t QUARTER = SORT_TILE / 4, TRIPS = QUARTER / 256;
+    constexpr uint32_t PER = NC / 256;  // contexts per thread in step 3
+    constexpr uint32_t KEY = 0xFFC01FFFu;  // context and pixel offset of a record
+    static_assert(SORT_TILE % 1024 == 0 && SORT_TILE <= (1u << 13), "four whole trips per wave; 13 bits of pixel offset");
+    static_assert(NC % 256 == 0 && NC <= 512, "a thread takes NC / 256 contexts; 9 bits of context");
+    __shared__ uint32_t srt[SORT_TILE + 1];   // the tile's events, contexts ascending, raster order inside (+ a sentinel behind the last)
+    __shared__ uint32_t stages[4][256];       // per wave: the events of one trip in raster order, on their way into registers
+    __shared__ uint32_t cnt[4][NC];           // per wave and context: count, then cursor into srt
+    __shared__ uint32_t gdst[NC];             // a context's run: its place among the tile's slots minus its place in srt
+    __shared__ uint32_t wsum[4];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();  // (uniform: see k_hist)
+    const uint32_t tid = threadIdx.x;
+    // Workgroup -> (plane, tile), XCD-aware (as k_scatter): all tiles of plane p on the XCD p % 8, in tile order -- the XCD whose
+    // k_enum, spine and pack workgroups read plane p's tiles later.  Placement only.
+    const uint32_t wg_tiles = tile_end - tile_begin;
+    const uint32_t item = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+    const uint32_t plane = xcd + 8u * (item / wg_tiles);
+    if (plane >= nplanes) return;  // (the whole workgroup)
+    const uint32_t tile = tile_begin + item % wg_tiles;
+    uint32_t *my_cnt = cnt[wave];
+    for (uint32_t c = lane; c < NC; c += 64) my_cnt[c] = 0;
+    const T *pl = planes + (uint64_t)plane * npix;
+    const uint32_t begin = tile * SORT_TILE;
+    const uint32_t qbegin = min(begin + wave * QUARTER, npix);
+    const uint32_t end = min(qbegin + QUARTER, npix);  // of this wave's quarter
+    uint32_t *stage = stages[wave];
+    const bool safe_rank = (mode & FRONT_SAFE_RANK) != 0;
+    // ---- 1. classify, compact, rank (k_scatter's step: static register slots, one returning LDS add per 64 events)
+    constexpr uint32_t BPT = 4, SLOTS = TRIPS * BPT;  // up to 256 events per trip
+    uint32_t rec[SLOTS], rk[SLOTS], nd[TRIPS];
+    auto is_interior = [&](uint32_t r, uint32_t x, uint32_t y) { return y > 0 && x + 256 <= W && r + 256 <= end; };  // (a span from the first column included)
+    Interior4<T> pre[TRIPS];
+    bool have[TRIPS];
+    {
+        uint32_t ri = qbegin, yi = qbegin / W, xi = qbegin - yi * W;
+#pragma unroll
+        for (uint32_t d = 0; d < TRIPS; d++) {
+            have[d] = ri < end && is_interior(ri, xi, yi);
+            if (have[d]) load_interior4(pl, ri, W, span_left_index(ri, xi, yi, W), pre[d]);
+            ri += 256;
+            xi += 256;
+            if (xi >= W) {  // (once per image row: scalar division)
+                const uint32_t q = xi / W;
+                yi += q;
+                xi -= q * W;
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t d = 0; d < TRIPS; d++) {
+        const uint32_t row0 = qbegin + d * 256;
+        uint32_t n = 0;  // events of this trip (wave-uniform)
+        if (have[d]) {
+            const uint32_t off0 = row0 - begin + 4 * lane;
+            PixelClass pc[4];
+            classify_loaded4(pre[d], pc);
+            uint32_t nev = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) nev += pc[j].cls != CLS_IN ? 1u : 0u;
+            const uint32_t incl = wave_incl_scan(nev);
+            uint32_t pos = incl - nev;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                if (pc[j].cls != CLS_IN) {
+                    stage[pos] = (pc[j].ctx << 22) | (pc[j].val << 13) | (off0 + j);
+                    pos++;
+                }
+            }
+            n = readlane(incl, 63);
+        } else {  // (a trip that crosses a row end, lies in the first row or ends the plane: the general neighbour rule)
+            bool evs[4];
+            uint32_t cs[4], es[4];
+            Coord xy;
+            xy.set(row0 + lane, W);
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t i = row0 + u * 64 + lane;
+                evs[u] = false;
+                cs[u] = 0;
+                es[u] = 0;
+                if (i < end && i >= 2) {
+                    const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
+                    evs[u] = pc.cls != CLS_IN;
+                    cs[u] = pc.ctx;
+                    es[u] = pc.val;
+                }
+                xy.advance(64, W);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {  // row by row, lane by lane
+                const uint64_t m = __ballot(evs[u]);
+                if (m == 0) continue;
+                if (evs[u]) stage[n + mbcnt(m)] = (cs[u] << 22) | (es[u] << 13) | (row0 - begin + u * 64 + lane);
+                n += (uint32_t)__popcll(m);
+            }
+        }
+        nd[d] = n;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t u = 0; u < BPT; u++) rec[d * BPT + u] = stage[u * 64 + lane];  // (past n: whatever the buffer held, not used)
+        if (!safe_rank) {
+#pragma unroll
+            for (uint32_t u = 0; u < BPT; u++) {
+                uint32_t r = 0;
+                if (u * 64 + lane < n) r = atomicAdd(&my_cnt[rec[d * BPT + u] >> 22], 1u);
+                rk[d * BPT + u] = r;
+            }
+        } else {
+            // ranks from ballots (k_scatter_ballot's way): every lane learns the lanes that hold its context, one ballot per
+            // context bit; its rank = the context's count so far + the lanes in front of it, the first lane of a context adds
+            // the batch's share to the count
+#pragma unroll
+            for (uint32_t u = 0; u < BPT; u++) {
+                const bool e = u * 64 + lane < n;
+                const uint32_t c = (rec[d * BPT + u] >> 22) & (NC - 1u);
+                const uint64_t ev_mask = __ballot(e);
+                uint32_t m_lo = (uint32_t)ev_mask, m_hi = (uint32_t)(ev_mask >> 32);
+                constexpr uint32_t CTX_BITS = NC == 256 ? 8 : 9;
+#pragma unroll
+                for (uint32_t b = 0; b < CTX_BITS; b++) {
+                    const uint32_t t = (uint32_t)((int32_t)(c << (31 - b)) >> 31);  // all ones if bit b of c is set
+                    const uint64_t bb = __ballot(e && t != 0);
+                    m_lo &= ~((uint32_t)bb ^ t);
+                    m_hi &= ~((uint32_t)(bb >> 32) ^ t);
+                }
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+                const uint32_t group = (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);
+                uint32_t r = 0;
+                if (e) r = my_cnt[c] + rank;
+                __builtin_amdgcn_wave_barrier();
+                if (e && rank == 0) my_cnt[c] = r + group;
+                __builtin_amdgcn_wave_barrier();
+                rk[d * BPT + u] = r;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // (the next trip writes the staging buffer again)
+    }
+    __syncthreads();
+    // ---- 3. the tile's layout: thread t takes contexts t * PER ..; two running sums in one register: the events in front (low
+    // half: the context's place in srt) and the slots in front (high half: every run rounded up to whole records)
+    const uint64_t pt = (uint64_t)plane * ntiles + tile;
+    uint32_t padpos[PER], nev_c[PER];
+    {
+        uint32_t n[4][PER], tot = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < PER; u++) {
+            nev_c[u] = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; w++) {
+                n[w][u] = cnt[w][tid * PER + u];
+                nev_c[u] += n[w][u];
+            }
+            tot += nev_c[u] | (((nev_c[u] + REC - 1u) & ~(REC - 1u)) << 16);
+        }
+        const uint32_t incl = wave_incl_scan(tot);  // (no carry between the halves: at most 4096 events)
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t at = incl - tot;
+        for (uint32_t w = 0; w < wave; w++) at += wsum[w];
+#pragma unroll
+        for (uint32_t u = 0; u < PER; u++) {
+            const uint32_t c = tid * PER + u;
+            uint32_t cs = at & 0xFFFFu;
+            const uint32_t ps = at >> 16;
+            padpos[u] = ps;
+            gdst[c] = ps - cs;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; w++) {
+                cnt[w][c] = cs;
+                cs += n[w][u];
+            }
+            at += nev_c[u] | (((nev_c[u] + REC - 1u) & ~(REC - 1u)) << 16);
+        }
+    }
+    const uint32_t both = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const uint32_t total = both & 0xFFFFu, slots = both >> 16;
+    if (tid == 0) srt[total] = 0xFFFFFFFFu;  // larger than any record's key: the last event has a successor to be compared with
+    const bool fits = slots <= cap;  // (if not: nothing of the tile is written, the host redoes the batch with the worst-case cap)
+    if (fits) {
+        // the run table (coalesced: a thread's PER contexts are neighbours) and the padding slots of this thread's runs
+        uint32_t *rt = runtab + pt * NC + tid * PER;
+#pragma unroll
+        for (uint32_t u = 0; u < PER; u++) rt[u] = (padpos[u] / REC) | (nev_c[u] << 16);
+        uint16_t *px = pix + pt * cap;
+#pragma unroll
+        for (uint32_t u = 0; u < PER; u++)
+            for (uint32_t i = nev_c[u]; i < ((nev_c[u] + REC - 1u) & ~(REC - 1u)); i++) px[padpos[u] + i] = 0xFFFFu;
+        if (tid == 0) tile_slots[pt] = slots;
+    } else {  // (an empty run table: the chain stage finds nothing of this tile)
+        uint32_t *rt = runtab + pt * NC + tid * PER;
+#pragma unroll
+        for (uint32_t u = 0; u < PER; u++) rt[u] = 0;
+        if (tid == 0) {
+            tile_slots[pt] = 0;
+            atomicOr(flags, TL_FLAG_OVERFLOW);
+        }
+    }
+    __syncthreads();
+    // ---- 4. place: where the context's events of this wave start + the event's rank among them
+#pragma unroll
+    for (uint32_t q0 = 0; q0 < SLOTS; q0 += 8) {
+        uint32_t at[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) at[q] = my_cnt[(rec[q0 + q] >> 22) & (NC - 1u)];  // (masked: an unused slot holds anything)
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++)
+            if (((q0 + q) % BPT) * 64 + lane < nd[(q0 + q) / BPT]) srt[at[q] + rk[q0 + q]] = rec[q0 + q];
+    }
+    __syncthreads();
+    // ---- 5. out, checked: (context, pixel offset) must ascend strictly -- exactly "stable partition by context"
+    uint32_t bad = mode & FRONT_TEST_VIOLATION;
+    if (fits) {
+        ET *evo = ev + pt * cap;
+        uint16_t *pxo = pix + pt * cap;
+        for (uint32_t j = tid; j < total; j += 256) {
+            const uint32_t r = srt[j], nxt = srt[j + 1];
+            const uint32_t dst = gdst[r >> 22] + j;
+            evo[dst] = (ET)((r >> 13) & 0x1FFu);
+            pxo[dst] = (uint16_t)(r & 0x1FFFu);
+            bad |= (nxt & KEY) <= (r & KEY) ? 1u : 0u;
+        }
+    }
+    if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(flags, TL_FLAG_ORDER);
+}
+
+// ------------------------------------------------------------------------------------------
 // resolve: replay KEstimator (parameter_selection.rs:49-85) along every chain.
 //
 // State S[k] = accumulated Rice lengths for k = 0..5 (traits.rs:26).  While no halving happens the
@@ -1182,34 +1423,6 @@ constexpr uint32_t TAG_SLICE_BITS = 5;  // a block's tag = epoch << 5 | slice of
 // blocks tagged with this launch's stamp (thread = block) and, per chain, the block whose events are in place but
 // which is not full yet (thread = chain, behind the block threads).
 // ------------------------------------------------------------------------------------------
-
-struct EstKeys {
-    uint32_t k0, k1, k2, k3, k4, k5, m;  // m = the smallest key (kept up to date by set / step)
-    __device__ __forceinline__ void set(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t s4, uint32_t s5) {
-        k0 = (s0 << 3) | 7u; k1 = (s1 << 3) | 6u; k2 = (s2 << 3) | 5u;
-        k3 = (s3 << 3) | 4u; k4 = (s4 << 3) | 3u; k5 = (s5 << 3) | 2u;
-        m = min_key();
-    }
-    __device__ __forceinline__ uint32_t min_key() const { return min(min(min(k0, k1), k2), min(min(k3, k4), k5)); }
-    // one event: returns 7 - k (k = get_k before the update), then update + halving
-    __device__ __forceinline__ uint32_t step(uint32_t e) {
-        const uint32_t r = m & 7u;
-        const uint32_t e8 = e << 3;
-        k0 += e8 + 8u;
-        k1 += ((e8 >> 1) & ~7u) + 16u;
-        k2 += ((e8 >> 2) & ~7u) + 24u;
-        k3 += ((e8 >> 3) & ~7u) + 32u;
-        k4 += ((e8 >> 4) & ~7u) + 40u;
-        k5 += ((e8 >> 5) & ~7u) + 48u;
-        m = min_key();
-        if (m >= (1025u << 3)) {  // x /= 2 on every counter (parameter_selection.rs:62)
-            k0 = ((k0 >> 1) & ~7u) | 7u; k1 = ((k1 >> 1) & ~7u) | 6u; k2 = ((k2 >> 1) & ~7u) | 5u;
-            k3 = ((k3 >> 1) & ~7u) | 4u; k4 = ((k4 >> 1) & ~7u) | 3u; k5 = ((k5 >> 1) & ~7u) | 2u;
-            m = min_key();
-        }
-        return r;
-    }
-};
 
 // replays block gb from its start state and stores the k of its 64 events (one 16-byte store per 16 events)
 template <typename ET>
@@ -2374,6 +2587,72 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 6))) __global__ __launch
     if (st < pack_tile_end) pack_tile_fused<T>(gsm, kq, fl, planes, fa, st, plane, gg);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_pack_t (round 5): the single-pass pack on the tile-local layout.  The tile's k bytes lie where the front kernel put the
+// tile's events -- kq[slot], pix[slot] = the event's pixel, slots [0, tile_slots) of the tile -- so the gather is one
+// contiguous read: four slots per thread and round, k dropped into the LDS array the pack stage indexes by pixel (padding
+// slots, pix = 0xFFFF, into a dump byte behind it).  No run table, no chains in this kernel.
+// ------------------------------------------------------------------------------------------
+struct TSources {
+    const uint8_t *kq;
+    const uint16_t *pix;
+    const uint32_t *tile_slots;
+    uint32_t cap, sort_ntiles;
+};
+
+template <typename T>
+__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 6))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_t(const T *__restrict__ planes, TSources ts, FusedArgs fa,
+                                                                                               uint32_t sort_tile_begin, uint32_t pack_tile_end) {
+    __shared__ alignas(16) uint8_t kq[PACK_TILE + 16];  // k of pixel tile_first + j (event pixels only: the others hold what was there); [PACK_TILE]: dump
+    __shared__ FusedLDS fl;
+    static_assert(SORT_TILE == PACK_TILE, "one workgroup = one sort tile = one pack tile (one look-back per workgroup)");
+    uint32_t x, plane;
+#ifdef FELICS_PACK_STAMPS
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 12; i++) fl.t_acc[i] = 0;
+        fl.t_last = __builtin_amdgcn_s_memtime();
+    }
+#endif
+    take_ticket(fa, fl, x, plane);
+    PSTAMP(0);
+    const uint32_t st = sort_tile_begin + x;
+    const T *pl = planes + (uint64_t)plane * fa.npix;
+    // ---- round trip 1: the tile's slots in use and the thread's pixels
+    const uint64_t pt = (uint64_t)plane * ts.sort_ntiles + st;
+    const uint32_t ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)ts.tile_slots[pt]);  // a multiple of REC
+    const GroupGeom gg = group_geometry<T>(pl, st, fa.W, fa.npix);
+    GroupSamples<T> gsm;
+    if (gg.fast) load_group(pl, st * PACK_TILE + threadIdx.x * PACK_PER_THREAD, fa.W, gsm);
+    for (uint32_t j = threadIdx.x; j < FUSED_WIN_WORDS + 2; j += PACK_THREADS) fl.win[j] = 0;  // the bit window (barrier: behind the gather)
+    PSTAMP(9);
+    // ---- round trip 2: k and pixel offsets of the tile's slots.  (A thread past the end takes the last four slots again -- the
+    // same k goes to the same pixels twice -- so the loads of a round run under no lane-wise condition.)
+    constexpr uint32_t GR = 3;  // rounds in flight together: 3072 slots (a 4K frame's tile has ~2400 in use)
+    const uint8_t *ksrc = ts.kq + pt * ts.cap;
+    const uint16_t *psrc = ts.pix + pt * ts.cap;
+    for (uint32_t s0 = 0; s0 < ns; s0 += GR * 4 * PACK_THREADS) {
+        uint32_t kv[GR];
+        uint2 pv[GR];
+#pragma unroll
+        for (uint32_t u = 0; u < GR; u++) {
+            const uint32_t s = min(s0 + u * 4 * PACK_THREADS + threadIdx.x * 4, ns - 4u);
+            kv[u] = *reinterpret_cast<const uint32_t *>(ksrc + s);
+            pv[u] = *reinterpret_cast<const uint2 *>(psrc + s);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < GR; u++) {
+            kq[min(pv[u].x & 0xFFFFu, PACK_TILE)] = (uint8_t)kv[u];
+            kq[min(pv[u].x >> 16, PACK_TILE)] = (uint8_t)(kv[u] >> 8);
+            kq[min(pv[u].y & 0xFFFFu, PACK_TILE)] = (uint8_t)(kv[u] >> 16);
+            kq[min(pv[u].y >> 16, PACK_TILE)] = (uint8_t)(kv[u] >> 24);
+        }
+    }
+    PSTAMP(2);
+    __syncthreads();
+    PSTAMP(3);
+    if (st < pack_tile_end) pack_tile_fused<T>(gsm, kq, fl, planes, fa, st, plane, gg);
+}
+
 // Words shared by two tiles (and the last, partly filled word of a plane): OR of the two halves.
 __global__ void k_join_edges(const uint64_t *__restrict__ tile_bitoff, const uint32_t *__restrict__ tile_bits,
                              const uint32_t *__restrict__ edge_first, const uint32_t *__restrict__ edge_last, PlaneOut po,
@@ -2636,6 +2915,39 @@ template void launch_pack_g<int16_t>(hipStream_t, const int16_t *, const uint8_t
                                      const uint32_t *, const uint32_t *, uint64_t *, uint64_t *, uint32_t *, uint64_t *,
                                      uint32_t *, uint32_t *, uint32_t *, const PackTarget &, const Geometry &, uint32_t,
                                      uint32_t, uint32_t, uint32_t *);
+
+template <typename T>
+void launch_pack_t(hipStream_t s, const T *planes, const uint8_t *kq, const uint16_t *pix, const uint32_t *tile_slots, uint32_t cap,
+                   uint64_t *status, uint64_t *tile_bitoff, uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first,
+                   uint32_t *edge_last, uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t st0, uint32_t st1, uint32_t epoch,
+                   uint32_t *ticket) {
+    if (st1 <= st0) return;
+    const FusedArgs fa{status, tile_bitoff, tile_bits, plane_carry, edge_first, edge_last, error,
+                       PlaneOut{to.out, to.slot_stride, to.scratch, to.plane_slot, g.planes_per_image},
+                       g.W, g.H, g.npix, g.pack_tiles, g.color, g.depth, epoch, ticket, g.nplanes};
+    const TSources ts{kq, pix, tile_slots, cap, g.sort_tiles};
+    // (the kernel takes its tile from the ticket, or from blockIdx.x of this one-dimensional grid: never from blockIdx.y)
+    FELICS_LAUNCH((k_pack_t<T>), dim3((st1 - st0) * g.nplanes), dim3(PACK_THREADS), s, planes, ts, fa, st0, g.pack_tiles);
+}
+template void launch_pack_t<uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, const uint16_t *, const uint32_t *, uint32_t, uint64_t *,
+                                     uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, const PackTarget &,
+                                     const Geometry &, uint32_t, uint32_t, uint32_t, uint32_t *);
+template void launch_pack_t<int16_t>(hipStream_t, const int16_t *, const uint8_t *, const uint16_t *, const uint32_t *, uint32_t, uint64_t *,
+                                     uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, const PackTarget &,
+                                     const Geometry &, uint32_t, uint32_t, uint32_t, uint32_t *);
+
+template <typename T, typename ET>
+void launch_front(hipStream_t s, const T *planes, const TileLocal<ET> &tl, const Geometry &g, uint32_t tile_begin, uint32_t tile_end,
+                  uint32_t *flags, uint32_t mode) {
+    if (tile_end <= tile_begin) return;
+    const dim3 grid(8u * cdiv(g.nplanes, 8) * (tile_end - tile_begin));  // one workgroup per tile, the planes dealt to the XCDs by the kernel
+    FELICS_LAUNCH((k_front<T, ET>), grid, dim3(256), s, planes, tl.ev, tl.pix, tl.runtab, tl.tile_slots, g.W, g.npix, g.sort_tiles, tile_begin,
+                  tile_end, g.nplanes, tl.cap, flags, mode);
+}
+template void launch_front<uint8_t, uint8_t>(hipStream_t, const uint8_t *, const TileLocal<uint8_t> &, const Geometry &, uint32_t, uint32_t,
+                                             uint32_t *, uint32_t);
+template void launch_front<int16_t, uint16_t>(hipStream_t, const int16_t *, const TileLocal<uint16_t> &, const Geometry &, uint32_t, uint32_t,
+                                              uint32_t *, uint32_t);
 
 void launch_join_edges_tiles(hipStream_t s, const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint32_t *edge_first,
                              const uint32_t *edge_last, const PackTarget &to, const Geometry &g, uint32_t ntiles) {

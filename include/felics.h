@@ -156,13 +156,16 @@ const char *felics_last_error(const felics_ctx *ctx);
  * holding the GPU for a second -- moves the context to the two-pass kernels for good; felics_last_error says so.) */
 typedef struct felics_stats {
     uint64_t submissions;        /* sub-batches queued so far */
-    uint64_t ticket_retries;     /* 0 or 1: a look-back gave up once and the context now hands its pack tiles out by ticket (first remedy) */
+    uint64_t ticket_retries;     /* 0 or 1: a look-back gave up and the context now hands its pack tiles out by ticket (first remedy) */
     uint64_t slot_overflows;     /* batches redone with exact placement: a stream outgrew its fixed slot */
     uint64_t lookback_fallbacks; /* batches redone because a tile gave up waiting for its predecessors */
     int two_pass;                /* 1: a ticketed look-back gave up as well: the context packs with the two-pass kernels from now on (slower) */
     int failed;                  /* 1: a wait for the GPU timed out; every further call returns FELICS_E_HIP */
-    uint64_t scatter_fallbacks;  /* 0 or 1: the event sort's check of its own output failed once; the batch was redone and the context ranks events with ballots from then on (slower, no assumption about the LDS) */
-    uint64_t sorted_event_sorts; /* sub-batches of 8-bit samples whose events were sorted by the LDS-sorted kernel (chosen by content: the rest used the ballot-ranked one) */
+    uint64_t scatter_fallbacks;  /* sub-batches redone because the front kernel's check of its own event order failed (with submissions in flight each
+                                    reports its own, so 0 .. lanes); the context ranks events with ballots from then on (slower, no assumption about the LDS) */
+    uint64_t sorted_event_sorts; /* sub-batches of 8-bit samples whose events were ranked with returning LDS atomics (the default), not with ballots */
+    uint64_t tile_overflows;     /* sub-batches redone because a tile's events outgrew the slots a tile gets by default; the context sizes its tiles for the
+                                    worst case from then on (more memory, same kernels) */
 } felics_stats;
 int felics_get_stats(const felics_ctx *ctx, felics_stats *out);
 

@@ -13,10 +13,13 @@ O=$R/felics_amd/_variants/$name
 mkdir -p "$O"
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter $*"
 cd "$SRC/felics_amd/csrc"
-for f in felics_kernels felics_wide felics_gpudecode; do hipcc $F -c $f.hip -o "$O/$f.o" & done
+KERNELS="felics_kernels felics_wide felics_gpudecode"
+[ -f felics_chain.hip ] && KERNELS="$KERNELS felics_chain"   # (round 5 on; an older checkout has no such file)
+OBJS=""
+for f in $KERNELS; do hipcc $F -c $f.hip -o "$O/$f.o" & OBJS="$OBJS $O/$f.o"; done
 hipcc $F -x hip -c felics_api.cpp -o "$O/felics_api.o" &
 hipcc -O3 -std=c++17 -fPIC -c felics_decode.cpp -o "$O/felics_decode.o" &
 wait
-hipcc --offload-arch=gfx950 -shared -o "$O/libfelics.so" "$O"/felics_kernels.o "$O"/felics_wide.o "$O"/felics_gpudecode.o "$O"/felics_api.o "$O"/felics_decode.o -Wl,-rpath,/opt/rocm/lib
+hipcc --offload-arch=gfx950 -shared -o "$O/libfelics.so" $OBJS "$O"/felics_api.o "$O"/felics_decode.o -Wl,-rpath,/opt/rocm/lib
 rm -f "$O"/*.o
 ls -la "$O/libfelics.so"

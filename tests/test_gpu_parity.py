@@ -277,17 +277,17 @@ def test_pack_variants(oracle):
 
     frames = [synth.gray8(1920, 1080, f, "S1") for f in range(16)] + [synth.gray8(1920, 1080, 3, "S2")]
     want = [oracle.compress(f) for f in frames]
-    # default: k in chain order from k_assign_serial, gathered by the single-pass pack (k_pack_g), tiles by workgroup index;
-    # a look-back that gives up switches to tiles by ticket (what FELICS_OWN_TAILS starts with), a second one to the two-pass
+    # default: k per record from k_assign3 into the tile's own slots, read back by the single-pass pack (k_pack_t), tiles by workgroup
+    # index; a look-back that gives up switches to tiles by ticket (what FELICS_OWN_TAILS starts with), a second one to the two-pass
     # kernels (k to a byte per pixel, lengths, bit scan, pack); FELICS_SERIAL / FELICS_TRACE are the profiling / debugging aids
     for env in ({}, {"FELICS_TWO_PASS": "1"}, {"FELICS_TEST_LOOKBACK_FAIL": "1"}, {"FELICS_OWN_TAILS": "1"},
                 {"FELICS_OWN_TAILS": "1", "FELICS_TEST_LOOKBACK_FAIL": "1"}, {"FELICS_LANES": "1"}, {"FELICS_LANES": "4", "FELICS_SLICES": "12"},
                 {"FELICS_SERIAL": "1", "FELICS_SLICES": "1"}, {"FELICS_TRACE": "1", "FELICS_TIMEOUT_S": "30"},
-                # the event sort: ranked with ballots from the start; the default's order check failing once (-> ballots);
-                # and both under the two-pass pack, which reads 32-bit pixel positions from the sort
-                {"FELICS_SCATTER": "ballot"}, {"FELICS_SCATTER": "sorted"}, {"FELICS_SCATTER": "sorted", "FELICS_TEST_SCATTER_ORDER": "1"},
-                {"FELICS_SCATTER": "sorted", "FELICS_TWO_PASS": "1"},
-                {"FELICS_SCATTER": "sorted", "FELICS_TEST_SCATTER_ORDER": "1", "FELICS_TWO_PASS": "1"}):
+                # the front kernel's ranks: from ballots from the start; the default's order check failing once (-> ballots), also
+                # under the two-pass pack; a tile that outgrows its slots (-> the batch again with worst-case tiles)
+                {"FELICS_SCATTER": "ballot"}, {"FELICS_TEST_SCATTER_ORDER": "1"}, {"FELICS_SCATTER": "ballot", "FELICS_TWO_PASS": "1"},
+                {"FELICS_TEST_SCATTER_ORDER": "1", "FELICS_TWO_PASS": "1"}, {"FELICS_TEST_TILE_CAP": "1"},
+                {"FELICS_TEST_TILE_CAP": "1", "FELICS_TWO_PASS": "1"}):
         os.environ.update(env)
         os.environ["FELICS_POISON"] = "1"
         try:
@@ -307,14 +307,15 @@ def test_pack_variants(oracle):
             else:
                 assert st["two_pass"] == (1 if "FELICS_TWO_PASS" in env else 0) and st["lookback_fallbacks"] == 0, (env, st)
             assert st["scatter_fallbacks"] == (1 if "FELICS_TEST_SCATTER_ORDER" in env else 0), (env, st)
+            assert st["tile_overflows"] == (1 if "FELICS_TEST_TILE_CAP" in env else 0), (env, st)
         finally:
             e.close()
 
 
-def test_event_sort_follows_content(oracle):
-    """A context sorts the events of a queued submission with k_scatter_ballot when the previous batch compressed below 3.6 bits
-    per sample, and with k_scatter (the default, always in blocking calls) otherwise (felics_api.cpp: scatter_mode).  Same bytes
-    either way."""
+def test_queued_submissions_of_changing_content(oracle):
+    """Queued submissions whose content changes from one to the next (flat, noise, smooth): the tile-local pipeline classifies a
+    pixel once whatever the content, every sub-batch's events are ranked by the front kernel's returning LDS atomics (its order
+    check never fires), no batch is redone."""
     import torch
     import felics_amd
     from felics_amd import synth
@@ -324,26 +325,30 @@ def test_event_sort_follows_content(oracle):
     smooth = [synth.gray8(1000, 700, f, "S1") for f in range(3)]
     e = felics_amd.Encoder(0)
     try:
-        assert e.compress_batch(flat) == [oracle.compress(f) for f in flat]      # blocking: sorted whatever the content
-        assert e.stats()["sorted_event_sorts"] == e.stats()["submissions"]
+        assert e.compress_batch(flat) == [oracle.compress(f) for f in flat]
         seq = (flat, flat, noise, noise, flat, noise, smooth)
         cap = 1000 * 700 * 3 * 2
-        d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
-        used_ballot = 0
-        for frames in seq:
-            before = e.stats()
-            d_in = torch.from_numpy(np.stack(frames)).cuda()
-            torch.cuda.synchronize()
-            offs, lens = e.wait_batch(e.submit_batch_device(d_in.data_ptr(), len(frames), 1000, 700, 0, 0, d_out.data_ptr(), cap))
-            host = d_out.cpu().numpy()
-            for i, f in enumerate(frames):
-                assert host[int(offs[i]): int(offs[i] + lens[i])].tobytes() == oracle.compress(f)
-            after = e.stats()
-            used_ballot += (after["submissions"] - before["submissions"]) - (after["sorted_event_sorts"] - before["sorted_event_sorts"])
-        # behind a flat batch -- submissions 1, 2, 3 and 6 of `seq` -- the ballot kernel
-        assert used_ballot == 4, (used_ballot, e.stats())
+        d_outs = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        d_ins = [torch.from_numpy(np.stack(frames)).cuda() for frames in seq]
+        torch.cuda.synchronize()
+        inflight = []
+
+        def finish(item):
+            i, t = item
+            offs, lens = e.wait_batch(t)
+            host = d_outs[i % 2].cpu().numpy()
+            for j, f in enumerate(seq[i]):
+                assert host[int(offs[j]): int(offs[j] + lens[j])].tobytes() == oracle.compress(f), (i, j)
+
+        for i, frames in enumerate(seq):  # two submissions in flight
+            if len(inflight) == 2:
+                finish(inflight.pop(0))
+            inflight.append((i, e.submit_batch_device(d_ins[i].data_ptr(), len(frames), 1000, 700, 0, 0, d_outs[i % 2].data_ptr(), cap)))
+        while inflight:
+            finish(inflight.pop(0))
         st = e.stats()
-        assert st["scatter_fallbacks"] == 0 and st["lookback_fallbacks"] == 0, st
+        assert st["sorted_event_sorts"] == st["submissions"], st
+        assert st["scatter_fallbacks"] == 0 and st["lookback_fallbacks"] == 0 and st["tile_overflows"] == 0 and st["slot_overflows"] == 0, st
     finally:
         e.close()
 

@@ -372,22 +372,22 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
     if (!ctx->scatter_ballot) ctx->stats.sorted_event_sorts++;
     for (int q = 0; q < ns; q++) {
         if (bounds[q + 1] != bounds[q]) {
-            StageTimer t(ctx, l, ST_SCATTER, f, true);
-            launch_front<T, ET>(f, d_planes, tloc, g, bounds[q], bounds[q + 1], d_flags, front_mode);
+            {
+                StageTimer t(ctx, l, ST_SCATTER, f, true);
+                launch_front<T, ET>(f, d_planes, tloc, g, bounds[q], bounds[q + 1], d_flags, front_mode);
+            }
+            // the slice's records in chain order: here, not on the spine stream, so that it runs beside the previous slice's walk
+            StageTimer t(ctx, l, ST_OFFSETS, f, true);
+            launch_enum(f, tloc.runtab, slice_of(q), g, bounds[q], bounds[q + 1], cap);
         }
         HIP_TRY(ctx, hipEventRecord(l.slice_done[q], f));
     }
-    // ---- spine stream: the slice's records in chain order, then the walk along every chain
+    // ---- spine stream: the walk along every chain
     for (int q = 0; q < ns; q++) {
         HIP_TRY(ctx, hipStreamWaitEvent(s, l.slice_done[q], 0));
         if (bounds[q + 1] != bounds[q]) {
-            const ChainSlice cs = slice_of(q);
-            {
-                StageTimer t(ctx, l, ST_OFFSETS, s, true);
-                launch_enum(s, tloc.runtab, cs, g, bounds[q], bounds[q + 1], cap);
-            }
             StageTimer t(ctx, l, ST_SPINE, s, true);
-            launch_spine3<ET>(s, tloc.ev, cs, chain_state, d_flags, g);
+            launch_spine3<ET>(s, tloc.ev, slice_of(q), chain_state, d_flags, g);
         }
         HIP_TRY(ctx, hipEventRecord(l.spine_done[q], s));
     }
@@ -893,6 +893,7 @@ int felics_ctx_create(int device, felics_ctx **out) {
     ctx->serial = getenv("FELICS_SERIAL") != nullptr;
     ctx->test_timeout = getenv("FELICS_TEST_TIMEOUT") != nullptr;
     if (const char *e = getenv("FELICS_SLICES")) ctx->slices_blocking = std::max(1, std::min(atoi(e), SLICES));
+    if (const char *e = getenv("FELICS_SLICES_QUEUED")) ctx->slices_queued = std::max(1, std::min(atoi(e), SLICES));  // (tuning sweeps: profiles/tools/sweep_queue.sh)
     ctx->trace = getenv("FELICS_TRACE") != nullptr;
     if (const char *e = getenv("FELICS_TIMEOUT_S")) ctx->timeout_s = std::max(1, atoi(e));
     bool ok = hipSetDevice(device) == hipSuccess;

@@ -27,62 +27,102 @@ namespace felics {
 static inline uint32_t cdiv_u(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // ------------------------------------------------------------------------------------------
-// k_enum: one wave per (chain, slice).  The chain of context c of plane p in this slice = the runs (tile, c) of the
-// slice's tiles in tile order, each cut into records of REC events.  Lane = tile (64 per round): records per tile from the
-// run table's column c, a wave scan for their places, one atomic per non-empty chain for its place in the slice's region.
-// Workgroup b -> four neighbouring contexts of one plane (their table entries share cache lines), all of plane p's
-// workgroups on the XCD p % 8 whose front workgroups wrote that plane's table (placement only).
+// k_enum: one workgroup per (chain, slice).  The chain of context c of plane p in this slice = the runs (tile, c) of the
+// slice's tiles in tile order, each cut into records of REC events; the chain's row of the run table is contiguous
+// (context-major).  All threads add up the row's records; one atomic per non-empty chain gives the chain its place in the
+// slice's region; then, 64 tiles (a "round") per wave at a time, the records are written 64 CONSECUTIVE records per store
+// instruction: lane = record, which finds its tile by bisection over the round's scanned record counts in LDS.  (A lane per
+// tile writing its own records one by one was one scattered 8-byte request per record: 0.7 ms per 64-frame step; one wave
+// per chain walked the hot chains' thousands of 64-record batches one after the other: 0.45 ms.)
+// All of plane p's workgroups on the XCD p % 8 whose front workgroups wrote that plane's table (placement only).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_enum(const uint32_t *__restrict__ runtab, uint2 *__restrict__ desc, uint2 *__restrict__ chain_seg,
                                               uint32_t *__restrict__ slice_nrec, uint32_t ntiles, uint32_t t0, uint32_t t1, uint32_t nplanes,
                                               uint32_t nctx, uint32_t cap_rec) {
+    constexpr uint32_t CHUNK_ROUNDS = 64;  // rounds whose totals are scanned together: 4096 tiles
+    __shared__ uint32_t sh_before[4][65 + 63], sh_first[4][64], sh_events[4][64];  // per wave (before: padded, the bisection may look one step past 64)
+    __shared__ uint32_t round_total[CHUNK_ROUNDS], wave_sum[4], sh_base;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
-    const uint32_t gpp = nctx / 4;  // workgroups per plane
     const uint32_t item = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
-    const uint32_t plane = xcd + 8u * (item / gpp);
+    const uint32_t plane = xcd + 8u * (item / nctx);
     if (plane >= nplanes) return;
-    const uint32_t ctx = (item % gpp) * 4 + wave;
+    const uint32_t ctx = item % nctx;
     const uint32_t chain = plane * nctx + ctx;
-    const uint32_t *col = runtab + (uint64_t)plane * ntiles * nctx + ctx;
+    const uint32_t *row = runtab + (uint64_t)chain * ntiles;  // the chain's runs, tile by tile
+    // ---- the chain's records in this slice
     uint32_t total = 0;
-    for (uint32_t tb = t0; tb < t1; tb += 256) {  // four rounds of loads in flight
-        uint32_t e[4];
-#pragma unroll
-        for (uint32_t u = 0; u < 4; u++) {
-            const uint32_t t = tb + u * 64 + lane;
-            e[u] = t < t1 ? col[(uint64_t)t * nctx] : 0u;
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < 4; u++) total += ((e[u] >> 16) + REC - 1) / REC;
-    }
-    total = readlane(wave_incl_scan(total), 63);
+    for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256) total += ((row[t] >> 16) + REC - 1) / REC;
+    total = wave_incl_scan(total);
+    if (lane == 63) wave_sum[wave] = total;
+    __syncthreads();
+    total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
     if (total == 0) {
-        if (lane == 0) chain_seg[chain] = make_uint2(0u, 0u);
+        if (threadIdx.x == 0) chain_seg[chain] = make_uint2(0u, 0u);
         return;
     }
-    uint32_t base = 0;
-    if (lane == 0) {
-        base = atomicAdd(slice_nrec, total);
+    if (threadIdx.x == 0) {
+        const uint32_t base = atomicAdd(slice_nrec, total);
         chain_seg[chain] = make_uint2(base, total);
+        sh_base = base;
     }
-    base = readlane(base, 0);
-    uint32_t run = base;
-    for (uint32_t tb = t0; tb < t1; tb += 64) {
-        const uint32_t t = tb + lane;
-        const uint32_t e = t < t1 ? col[(uint64_t)t * nctx] : 0u;
-        const uint32_t n = e >> 16, nr = (n + REC - 1) / REC;
-        const uint32_t incl = wave_incl_scan(nr);
-        const uint32_t at = run + incl - nr;
-        const uint32_t r0 = (plane * ntiles + t) * cap_rec + (e & 0xFFFFu);  // first record of the run, over the whole sub-batch
-        for (uint32_t j = 0; j < nr; j++) desc[at + j] = make_uint2(r0 + j, min(REC, n - j * REC));
-        run += readlane(incl, 63);
+    __syncthreads();
+    uint32_t carry = sh_base;  // records in front of the chunk
+    uint32_t *before = sh_before[wave];  // [i]: records of the round's tiles in front of tile i; [64]: all of them
+    uint32_t *first = sh_first[wave];    // [i]: the run's first record over the whole sub-batch
+    uint32_t *events = sh_events[wave];  // [i]: its events
+    for (uint32_t c0 = t0; c0 < t1; c0 += CHUNK_ROUNDS * 64) {
+        // the rounds of this chunk: wave w takes rounds w, w + 4, ...; their totals first, scanned by wave 0
+        const uint32_t nrounds = min(CHUNK_ROUNDS, (t1 - c0 + 63u) / 64u);
+        for (uint32_t r = wave; r < nrounds; r += 4) {
+            const uint32_t t = c0 + r * 64 + lane;
+            const uint32_t nr = t < t1 ? ((row[t] >> 16) + REC - 1) / REC : 0u;
+            const uint32_t incl = wave_incl_scan(nr);
+            if (lane == 63) round_total[r] = incl;
+        }
+        __syncthreads();
+        uint32_t rt = 0;
+        if (wave == 0) {
+            rt = lane < nrounds ? round_total[lane] : 0u;
+            const uint32_t incl = wave_incl_scan(rt);
+            round_total[lane] = incl - rt;  // now: records of the chunk in front of round `lane`
+            if (lane == 63) wave_sum[0] = incl;
+        }
+        __syncthreads();
+        for (uint32_t r = wave; r < nrounds; r += 4) {
+            const uint32_t t = c0 + r * 64 + lane;
+            const uint32_t e = t < t1 ? row[t] : 0u;
+            const uint32_t n = e >> 16, nr = (n + REC - 1) / REC;
+            const uint32_t incl = wave_incl_scan(nr);
+            const uint32_t total_r = readlane(incl, 63);
+            if (total_r == 0) continue;
+            const uint32_t run = carry + round_total[r];
+            __builtin_amdgcn_wave_barrier();  // (the previous round's reads are done)
+            before[lane] = incl - nr;
+            if (lane == 0) before[64] = total_r;
+            first[lane] = (plane * ntiles + t) * cap_rec + (e & 0xFFFFu);
+            events[lane] = n;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i0 = 0; i0 < total_r; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                // the last tile with before[tile] <= i: six halvings of [0, 64)
+                uint32_t lo = 0;
+#pragma unroll
+                for (uint32_t step = 32; step != 0; step >>= 1)
+                    if (before[lo + step] <= i) lo += step;
+                const uint32_t j = i - before[lo];
+                if (i < total_r) desc[run + i] = make_uint2(first[lo] + j, min(REC, events[lo] - j * REC));
+            }
+        }
+        carry += wave_sum[0];
+        __syncthreads();  // (round_total and wave_sum are written again)
     }
 }
 
 void launch_enum(hipStream_t s, const uint32_t *runtab, const ChainSlice &cs, const Geometry &g, uint32_t tile_begin, uint32_t tile_end,
                  uint32_t cap) {
     if (tile_end <= tile_begin) return;
-    const dim3 grid(8u * cdiv_u(g.nplanes, 8) * (g.nctx / 4));
+    const dim3 grid(8u * cdiv_u(g.nplanes, 8) * g.nctx);
     FELICS_LAUNCH(k_enum, grid, dim3(256), s, runtab, cs.desc, cs.chain_seg, cs.nrec, g.sort_tiles, tile_begin, tile_end, g.nplanes, g.nctx,
                   cap / REC);
 }
@@ -108,6 +148,34 @@ void launch_enum(hipStream_t s, const uint32_t *runtab, const ChainSlice &cs, co
 // walks window w.  Chains with fewer than SP3_MULTI_MIN windows to walk in this launch are done by one wave, step by step.
 // ------------------------------------------------------------------------------------------
 
+#ifdef FELICS_SPINE_STAMPS
+// Diagnostic build only (profiles/tools/spine_stamps.py): s_memtime ticks of the two waves of ONE chain (context 1 of plane 0, the
+// longest of an S1 frame): [0] walker waiting at the hand-over barrier, [1] walker walking, [2] helper working, [3] helper waiting,
+// [4] halvings, [5] windows, [7] the walker's whole life.
+__device__ unsigned long long g_spine_stamps[8];
+extern "C" __attribute__((visibility("default"))) int felics_debug_spine_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spine_stamps), sizeof(g_spine_stamps)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_spine_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define SP3_STAMP(i)                                                        \
+    do {                                                                    \
+        if (stamped) {                                                      \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+            st_acc[i] += now_ - st_last;                                    \
+            st_last = now_;                                                 \
+        }                                                                   \
+    } while (0)
+#else
+#define SP3_STAMP(i)
+#endif
+
+#ifndef FELICS_SP3_EXP
+#define FELICS_SP3_EXP 0
+#endif
 constexpr uint32_t SP3_ROW = REC * 3 + 1;   // dwords per record in pref (odd: the helper's 64 rows start in different banks)
 constexpr uint32_t SP3_CROW = 9;            // dwords per row of cumT (odd, likewise)
 constexpr uint32_t SP3_MULTI_MIN = 3;       // windows
@@ -121,6 +189,7 @@ struct Spine3LDS {
 };
 
 typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 // both 16-bit halves of p >= the halves of theta
 __device__ __forceinline__ bool pk_all_ge(uint32_t p, uint32_t theta) {
     const pk_u16 a = __builtin_bit_cast(pk_u16, p), b = __builtin_bit_cast(pk_u16, theta);
@@ -150,20 +219,30 @@ __device__ __forceinline__ uint32_t record_event(const RecEvents<ET> &r, uint32_
     return sizeof(ET) == 1 ? (word >> sh) & 0xFFu : (word >> sh) & 0xFFFFu;
 }
 
+// Event t of a record twice in one register (low and high half): one v_perm of the dword that holds it.
+template <typename ET>
+__device__ __forceinline__ uint32_t record_event_twice(const RecEvents<ET> &r, uint32_t t) {
+    constexpr uint32_t EPW = 4 / sizeof(ET);
+    const uint32_t word = r.w[t / EPW], i = t % EPW;
+    if (sizeof(ET) == 1) return __builtin_amdgcn_perm(0u, word, 0x0c000c00u + i * 0x00010001u);  // bytes {i, 0, i, 0}
+    return __builtin_amdgcn_perm(0u, word, i == 0 ? 0x01000100u : 0x03020302u);                  // halfword i twice
+}
+
 // helper, window w: prefix sums of lane's record (its events in `e`, `n` of them; n = 0 behind the chain's last record) and
-// the window's cumulative sums
+// the window's cumulative sums.  The Rice lengths of an event for k = 0..5, (e >> k) + 1 + k (rice_coding.rs:56-58), two to a
+// register: three packed 16-bit shifts of the event held twice; the constant parts ride along in the running sums' adds.
 template <typename ET>
 __device__ __forceinline__ void spine3_produce(Spine3LDS &sh, uint32_t w, const RecEvents<ET> &e, uint32_t n, uint32_t rec) {
     const uint32_t lane = lane_id();
     uint32_t *prow = sh.pref[w & 1u] + lane * SP3_ROW;
     uint32_t a01 = 0, a23 = 0, a45 = 0;
+    const pk_u16 s01 = {0, 1}, s23 = {2, 3}, s45 = {4, 5};
 #pragma unroll
     for (uint32_t t = 0; t < REC; t++) {
-        uint32_t l01, l23, l45;
-        packed_lengths(record_event(e, t), l01, l23, l45);
-        a01 += l01;
-        a23 += l23;
-        a45 += l45;
+        const pk_u16 e2 = __builtin_bit_cast(pk_u16, record_event_twice(e, t));
+        a01 += __builtin_bit_cast(uint32_t, (pk_u16)(e2 >> s01)) + 0x00020001u;
+        a23 += __builtin_bit_cast(uint32_t, (pk_u16)(e2 >> s23)) + 0x00040003u;
+        a45 += __builtin_bit_cast(uint32_t, (pk_u16)(e2 >> s45)) + 0x00060005u;
         prow[t * 3] = a01;
         prow[t * 3 + 1] = a23;
         prow[t * 3 + 2] = a45;
@@ -185,55 +264,111 @@ __device__ __forceinline__ void spine3_produce(Spine3LDS &sh, uint32_t w, const 
     sh.grec[w % 3u][lane] = rec;
 }
 
-// walker, window w: Sv = the state at the window's start on entry, at its end on return.  Returns false if an invariant of
-// the search broke (never seen: it would mean the helper's sums and prefix sums disagree).
+// walker, window w: Sv = the state at the window's start on entry, at its end on return (lane l: S[l & 7]; entries 6, 7 hold
+// nothing that is read).  Returns false if an invariant of the search broke (never seen: it would mean the helper's sums and
+// prefix sums disagree).
+//
+// Written for the length of its dependent instruction chain -- every halving of a chain goes through this loop, one after the
+// other, and a lone wave pays 7-10 cycles per dependent instruction, more where a value crosses between the vector and the
+// scalar unit (profiles/r05/spine_stamps.txt) -- so:
+//   * one crossing per search: the six compares of a record are six subtractions and a signed three-way minimum on the vector
+//     unit, ONE compare makes the mask; inside the record three saturating packed subtractions, an OR, one compare;
+//   * what does not need the record's prefix sums runs while they are on their way from LDS: the thresholds inside the record
+//     (theta_k minus the cumulative sum in front of the record: every lane computes them for ITS record from the exclusive
+//     sums it holds, the record f's are read from lane f), and what the previous halving leaves behind for the helper.
 __device__ __forceinline__ bool spine3_walk(Spine3LDS &sh, uint32_t w, uint32_t &Sv) {
     const uint32_t lane = lane_id(), l7 = lane & 7u;
-    const uint32_t sh16 = (l7 & 1u) << 4;
+    // lane l takes counter l & 7 out of the packed prefix sums at the halving: a mask per register (its own 16-bit field of its
+    // own register, nothing of the others), a shift
+    const uint32_t sh16 = (l7 & 1u) << 4, field = 0xFFFFu << sh16;
+    const uint32_t M01 = l7 < 2 ? field : 0u, M23 = (l7 & 6u) == 2 ? field : 0u, M45 = (l7 & 6u) == 4 ? field : 0u;
     const uint32_t *cT = sh.cumT[w % 3u];
-    const uint32_t *pf = sh.pref[w & 1u];
-    uint32_t *lD = sh.lastD[w & 1u];
-    const uint32_t c0 = cT[(lane + 1) * SP3_CROW], c1 = cT[(lane + 1) * SP3_CROW + 1], c2 = cT[(lane + 1) * SP3_CROW + 2];
-    const uint32_t c3 = cT[(lane + 1) * SP3_CROW + 3], c4 = cT[(lane + 1) * SP3_CROW + 4], c5 = cT[(lane + 1) * SP3_CROW + 5];
-    const uint32_t totalv = l7 < 6 ? cT[64 * SP3_CROW + l7] : 0u;  // the window's sums (state-vector layout)
-    if (lane < 8) lD[lane] = Sv;  // row 0: the carry-in (base 0)
+    const uint32_t *pf = sh.pref[w & 1u] + (lane & (REC - 1u)) * 3;
+    const uint32_t *cTv = cT + l7;  // row r, this lane's counter (words 6 .. 8 of a row: zero)
+    uint32_t *lD = sh.lastD[w & 1u] + l7;
+    // the cumulative sums through record `lane` (c) and in front of it (x)
+    const uint32_t *cin = cT + (lane + 1) * SP3_CROW, *cex = cT + lane * SP3_CROW;
+    const uint32_t c0 = cin[0], c1 = cin[1], c2 = cin[2], c3 = cin[3], c4 = cin[4], c5 = cin[5];
+    const uint32_t x0 = cex[0], x1 = cex[1], x2 = cex[2], x3 = cex[3], x4 = cex[4], x5 = cex[5];
+    const uint32_t totalv = cTv[64 * SP3_CROW];  // the window's sums (state-vector layout)
+    if (lane < 8) lD[0] = Sv;  // row 0: the carry-in (base 0)
+    // The recurrence, arranged for depth (a dependent step costs a lone wave ~20 cycles whatever the unit:
+    // profiles/r05/dep_latency.txt).  With u = S - base (kept instead of S and base) and, at a halving, nb = the cumulative
+    // sums there: S' = (u + nb) >> 1, and the next thresholds theta' = nb + max(1025 - S', 0) = max((nb + 2051 - u) >> 1, nb)
+    // (signed, arithmetic shift): three steps behind the prefix sums at the halving instead of six.
+    const uint32_t pf_at = (uint32_t)(uintptr_t)(const lds_u32 *)pf, cTv_at = (uint32_t)(uintptr_t)(const lds_u32 *)cTv;  // LDS addresses
+    uint32_t uv = Sv;       // S - base
     uint32_t basev = 0;
     uint64_t hm = 0;
-    bool ok = true;
+    uint32_t lost = 0;  // a search inside a record found nothing: the helper's sums and prefix sums disagree (reported, not acted on)
     // (bounded: a window holds at most 1024 halvings -- one per event -- and a wave that spins on a broken invariant takes
     // the GPU with it)
-    for (uint32_t guard = 0; guard < 64 * REC + 1; guard++) {
-        // theta_k = base_k + max(1025 - S_k, 0)
-        const uint32_t theta = basev + (uint32_t)max(1025 - (int)Sv, 0);
+    int guard = 64 * REC;  // (goes negative when the bound is reached: no record "reaches" anything then, the loop ends)
+    uint32_t t01, t23, t45;
+    // the records whose six cumulative sums have all reached theta: the first one holds the next halving.  Behind the compare
+    // (in the shadow of its way to the scalar unit and back): the thresholds inside every lane's own record -- theta_k minus the
+    // cumulative sum in front of the record, two to a register -- of which record f's will be read from lane f.
+    auto reached = [&](uint32_t theta) {
         const uint32_t T0 = readlane(theta, 0), T1 = readlane(theta, 1), T2 = readlane(theta, 2);
         const uint32_t T3 = readlane(theta, 3), T4 = readlane(theta, 4), T5 = readlane(theta, 5);
-        const uint64_t q = __ballot(c0 >= T0 && c1 >= T1 && c2 >= T2 && c3 >= T3 && c4 >= T4 && c5 >= T5);
-        if (q == 0) break;  // no further halving in this window
+        const int d012 = min(min((int)(c0 - T0), (int)(c1 - T1)), (int)(c2 - T2));
+        const int d345 = min(min((int)(c3 - T3), (int)(c4 - T4)), (int)(c5 - T5));
+        const uint64_t r = __ballot(min(min(d012, d345), guard) >= 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t a0 = __builtin_elementwise_sub_sat(T0, x0), a1 = __builtin_elementwise_sub_sat(T1, x1);
+        const uint32_t a2 = __builtin_elementwise_sub_sat(T2, x2), a3 = __builtin_elementwise_sub_sat(T3, x3);
+        const uint32_t a4 = __builtin_elementwise_sub_sat(T4, x4), a5 = __builtin_elementwise_sub_sat(T5, x5);
+        t01 = a0 | (a1 << 16);
+        t23 = a2 | (a3 << 16);
+        t45 = a4 | (a5 << 16);
+        return r;
+    };
+    uint64_t q = reached((uint32_t)max(1025 - (int)Sv, 0));  // theta_k = base_k + max(1025 - S_k, 0), base = 0
+    uint32_t pend_row = 0, pend_val = 0;  // what the last halving leaves for the helper: stored while the next one's reads are in flight
+    bool pending = false;
+    while (q != 0) {
         const uint32_t f = (uint32_t)__builtin_ctzll(q);
-        const uint32_t *prow = pf + f * SP3_ROW + (lane & (REC - 1u)) * 3;
+        uint32_t prow_at, crow_at;  // (one multiply-add each, on the vector unit: a scalar multiply and a vector add are two steps)
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(prow_at) : "s"(f), "v"(SP3_ROW * 4u), "v"(pf_at));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(crow_at) : "s"(f), "v"(SP3_CROW * 4u), "v"(cTv_at));
+        const lds_u32 *prow = (const lds_u32 *)(uintptr_t)prow_at;
         const uint32_t p01 = prow[0], p23 = prow[1], p45 = prow[2];
-        const uint32_t cprev = l7 < 6 ? cT[f * SP3_CROW + l7] : 0u;  // through record f - 1
-        // thresholds inside the record, two to a register: lane 0 -> k = 0, 1; lane 2 -> 2, 3; lane 4 -> 4, 5
-        const uint32_t thp = (uint32_t)max((int)(theta - cprev), 0);
-        const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)thp, 0x101, 0xF, 0xF, true);  // row_shl:1
-        const uint32_t th2 = thp | (up << 16);
-        const uint32_t T01 = readlane(th2, 0), T23 = readlane(th2, 2), T45 = readlane(th2, 4);
-        const uint64_t m = __ballot(pk_all_ge(p01, T01) && pk_all_ge(p23, T23) && pk_all_ge(p45, T45)) & 0xFFFFull;
-        if (m == 0) {
-            ok = false;
-            break;
-        }
-        const uint32_t ts = (uint32_t)__builtin_ctzll(m);
-        const uint32_t q01 = readlane(p01, ts), q23 = readlane(p23, ts), q45 = readlane(p45, ts);
-        const uint32_t qv = l7 < 2 ? q01 : l7 < 4 ? q23 : q45;
-        const uint32_t Pf = l7 < 6 ? (qv >> sh16) & 0xFFFFu : 0u;
-        const uint32_t nb = cprev + Pf;   // the window's cumulative sums at the halving
-        Sv = (Sv + nb - basev) >> 1;      // x /= 2 on every counter (parameter_selection.rs:62)
-        basev = nb;
-        if (lane < 8) lD[(f + 1) * 8 + lane] = Sv - basev;
+        const uint32_t cprev = *(const lds_u32 *)(uintptr_t)crow_at;  // through record f - 1
+        __builtin_amdgcn_sched_barrier(0);  // (the reads are issued; everything below up to the first use of p01 runs in their shadow)
+        const uint32_t T01 = readlane(t01, f), T23 = readlane(t23, f), T45 = readlane(t45, f);  // the thresholds inside record f
+        if (pending && lane < 8) lD[pend_row] = pend_val;
         hm |= 1ull << f;
+        guard--;
+        const uint32_t u2051 = 2051u - uv;
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t B1 = cprev + u2051, ucp = cprev + uv;  // (beside the search: they need cprev only)
+        const pk_u16 z01 = __builtin_elementwise_sub_sat(__builtin_bit_cast(pk_u16, T01), __builtin_bit_cast(pk_u16, p01));
+        const pk_u16 z23 = __builtin_elementwise_sub_sat(__builtin_bit_cast(pk_u16, T23), __builtin_bit_cast(pk_u16, p23));
+        const pk_u16 z45 = __builtin_elementwise_sub_sat(__builtin_bit_cast(pk_u16, T45), __builtin_bit_cast(pk_u16, p45));
+        const uint32_t z = __builtin_bit_cast(uint32_t, z01) | __builtin_bit_cast(uint32_t, z23) | __builtin_bit_cast(uint32_t, z45);
+        // the record's events at which all six prefix sums have reached their thresholds (lanes 16 .. 63 repeat lanes 0 .. 15: the
+        // lowest set bit is the first such event)
+        const uint32_t m = (uint32_t)__ballot(z == 0);
+        lost |= ((m & 0xFFFFu) - 1u) >> 31;  // m == 0
+        const uint32_t ts = (uint32_t)__builtin_ctz(m) & 31u;
+        const uint32_t q01 = readlane(p01, ts), q23 = readlane(p23, ts), q45 = readlane(p45, ts);
+        const uint32_t Pf = ((q01 & M01) | (q23 & M23) | (q45 & M45)) >> sh16;
+        const uint32_t nb = cprev + Pf;   // the window's cumulative sums at the halving
+        const uint32_t theta = (uint32_t)max((int)(B1 + Pf) >> 1, (int)nb);
+        Sv = (ucp + Pf) >> 1;             // x /= 2 on every counter (parameter_selection.rs:62)
+        uv = Sv - nb;
+        basev = nb;
+        pend_row = (uint32_t)__builtin_amdgcn_readfirstlane((int)((f + 1) * 8));
+        pend_val = uv;
+        pending = true;
+        q = reached(theta);
     }
+    if (pending && lane < 8) lD[pend_row] = pend_val;
+    const bool ok = lost == 0 && guard >= 0;
     Sv += totalv - basev;
+#ifdef FELICS_SPINE_STAMPS
+    if (lane == 0) atomicAdd(&g_spine_stamps[6], (unsigned long long)(64 * REC - guard));  // halvings of ALL chains
+#endif
     if (lane == 0) {
         sh.hmask[w & 1u][0] = (uint32_t)hm;
         sh.hmask[w & 1u][1] = (uint32_t)(hm >> 32);
@@ -277,8 +412,20 @@ __global__ __launch_bounds__(128) void k_spine3(const ET *__restrict__ ev, const
     const uint2 *dsc = desc + rec0;
     uint4 *out = state16 + rec0;
     uint32_t *cstate = chain_state + (uint64_t)chain * 8;
-    // row 0 of every cumT buffer: zeros (the window's sums in front of its first record)
-    if (wave == 0 && lane < 3 * SP3_CROW) sh.cumT[lane / SP3_CROW][lane % SP3_CROW] = 0;
+    // cumT: row 0 of every buffer is zeros (the window's sums in front of its first record), and so are the words behind the
+    // six counters in every row (the walker reads a row as a state vector of eight); nobody writes them again
+    if (wave == 0) {
+        for (uint32_t i = lane; i < 3 * 66; i += 64) {
+            uint32_t *row = sh.cumT[i / 66] + (i % 66) * SP3_CROW;
+            row[6] = 0;
+            row[7] = 0;
+            row[8] = 0;
+            if (i % 66 == 0) {
+#pragma unroll
+                for (uint32_t k = 0; k < 6; k++) row[k] = 0;
+            }
+        }
+    }
     auto fetch_desc = [&](uint32_t w) {
         const uint32_t r = w * 64 + lane;
         return r < nrec ? dsc[r] : make_uint2(0u, 0u);  // (behind the last record: no events; record 0 of the batch is there to be read)
@@ -315,26 +462,65 @@ __global__ __launch_bounds__(128) void k_spine3(const ET *__restrict__ ev, const
         asm volatile("; state in %0" : "+v"(Sv));
         __builtin_amdgcn_s_setprio(3);  // a chain is one long dependent instruction stream: never make it wait for issue
         bool ok = true;
+#ifdef FELICS_SPINE_STAMPS
+        const bool stamped = ctx == 1 && plane == 0;
+        unsigned long long st_acc[4] = {}, st_last = __builtin_amdgcn_s_memtime();
+        const unsigned long long st_begin = st_last;
+#endif
         for (uint32_t it = 0; it < nwin + 2; it++) {
             if (it >= 1 && it <= nwin) ok = spine3_walk(sh, it - 1, Sv) && ok;
+            SP3_STAMP(1);
             __syncthreads();
+            SP3_STAMP(0);
         }
+#ifdef FELICS_SPINE_STAMPS
+        if (stamped && lane == 0) {
+            atomicAdd(&g_spine_stamps[0], st_acc[0]);
+            atomicAdd(&g_spine_stamps[1], st_acc[1]);
+            atomicAdd(&g_spine_stamps[5], (unsigned long long)nwin);
+            atomicAdd(&g_spine_stamps[7], __builtin_amdgcn_s_memtime() - st_begin);
+        }
+#endif
         if (lane < 6) cstate[lane] = Sv;
         if (!ok && lane == 0) atomicOr(flags, TL_FLAG_SPINE);
     } else {
-        uint2 dcur = fetch_desc(0), dnxt = fetch_desc(1);
-        RecEvents<ET> ecur, enxt;
-        load_record(ev, dcur.x, ecur);
+        __builtin_amdgcn_s_setprio(2);  // the walker waits for this wave at every hand-over: in front of the other kernels' waves on its SIMD
+        // The events of a window are asked for three hand-overs before they are needed, their places (desc) five: with the GPU full
+        // of other kernels a load takes microseconds, and a helper that waits for its events holds up the walker (one window
+        // ahead, the helper of the longest chain spent 7 250 cycles per window beside a full batch and 2 500 alone:
+        // profiles/r05/spine_stamps.txt).
+        uint2 d0 = fetch_desc(0), d1 = fetch_desc(1), d2 = fetch_desc(2), d3 = fetch_desc(3), d4 = fetch_desc(4);
+        RecEvents<ET> e0, e1, e2, e3;
+        load_record(ev, d0.x, e0);
+        load_record(ev, d1.x, e1);
+        load_record(ev, d2.x, e2);
+#ifdef FELICS_SPINE_STAMPS
+        const bool stamped = ctx == 1 && plane == 0;
+        unsigned long long st_acc[4] = {}, st_last = __builtin_amdgcn_s_memtime();
+#endif
         for (uint32_t it = 0; it < nwin + 2; it++) {
-            const uint2 dnn = fetch_desc(it + 2);  // (windows past the last: no records, nothing read)
-            load_record(ev, dnxt.x, enxt);
+            const uint2 d5 = fetch_desc(it + 5);  // (windows past the last: no records, nothing read)
+            load_record(ev, d3.x, e3);
             if (it >= 2) spine3_finish(sh, it - 2, min(64u, nrec - (it - 2) * 64), out + (uint64_t)(it - 2) * 64);
-            if (it < nwin) spine3_produce<ET>(sh, it, ecur, dcur.y, dcur.x);
-            ecur = enxt;
-            dcur = dnxt;
-            dnxt = dnn;
+            if (it < nwin) spine3_produce<ET>(sh, it, e0, d0.y, d0.x);
+            e0 = e1;
+            e1 = e2;
+            e2 = e3;
+            d0 = d1;
+            d1 = d2;
+            d2 = d3;
+            d3 = d4;
+            d4 = d5;
+            SP3_STAMP(2);
             __syncthreads();
+            SP3_STAMP(3);
         }
+#ifdef FELICS_SPINE_STAMPS
+        if (stamped && lane == 0) {
+            atomicAdd(&g_spine_stamps[2], st_acc[2]);
+            atomicAdd(&g_spine_stamps[3], st_acc[3]);
+        }
+#endif
     }
 }
 

@@ -11,15 +11,15 @@
 namespace felics {
 
 // Contexts (H - L of a pixel's two neighbours, traits.rs:28): 0..255 for u8 samples, 0..510 for the Y/Co/Cg planes of
-// RGB8 (table padded to 512).  NCTX sizes what is shared by both (LDS tables, upper bounds); the per-tile count matrix,
-// the chain tables and the spine's grid use the sample type's own count, nctx_of<T>() = Geometry::nctx.
+// RGB8 (table padded to 512).  NCTX sizes what is shared by both (upper bounds); the run table, the chain tables and the
+// spine's grid use the sample type's own count, nctx_of<T>() = Geometry::nctx.
 constexpr uint32_t NCTX = 512;
 template <typename T>
 constexpr uint32_t nctx_of() {
     return sizeof(T) == 1 ? 256u : 512u;  // T = sample type (u8 / i16) or event type (u8 / u16)
 }
-// pixels one wave partitions by context in the hist / scatter stages.  Equal to the pack tile: the pack stage
-// gathers k for exactly its own tile's events (k_pack_g), one look-back per workgroup.
+// pixels one workgroup sorts by context in the front stage.  Equal to the pack tile: the pack stage reads back k for exactly
+// its own tile's events (k_pack_t), one look-back per workgroup.
 constexpr uint32_t SORT_TILE = 4096;
 // pack stage: 256 threads x 16 consecutive pixels
 constexpr uint32_t PACK_THREADS = 256;
@@ -98,7 +98,7 @@ struct TileLocal {
     ET *ev;                // [slot] value to Rice-code
     uint16_t *pix;         // [slot] the event's pixel: offset in its tile; 0xFFFF in padding slots
     uint8_t *kq;           // [slot] k of the event (k_assign3)
-    uint32_t *runtab;      // [(plane * sort_tiles + tile) * nctx + c] = first record of the tile's run of c (in the tile) | events << 16
+    uint32_t *runtab;      // [(plane * nctx + c) * sort_tiles + tile] = first record of the tile's run of c (in the tile) | events << 16
     uint32_t *tile_slots;  // [plane * sort_tiles + tile] slots in use (a multiple of REC)
     uint32_t cap;          // slots per tile
 };
@@ -125,50 +125,8 @@ void launch_assign3(hipStream_t s, const ET *ev, const ChainSlice &cs, uint8_t *
 void launch_k_to_pixels_tl(hipStream_t s, const uint8_t *kq, const uint16_t *pix, const uint32_t *tile_slots, uint32_t cap, uint8_t *k_map,
                            const Geometry &g);
 
-template <typename T>
-void launch_hist(hipStream_t s, const T *planes, uint32_t *counts, const Geometry &g);
-
-void launch_offsets(hipStream_t s, uint32_t *counts, uint32_t *chain_len, uint32_t *chain_base,
-                    uint32_t *total_events, const Geometry &g);
-
-// scatter works on a slice [tile_begin, tile_end) of every plane's tiles
-template <typename T, typename ET>
-void launch_scatter(hipStream_t s, const T *planes, const uint32_t *tile_off, const uint32_t *chain_base,
-                    ET *sorted_e, uint32_t *pix_of, bool in_tile_offsets, const Geometry &g, uint32_t tile_begin, uint32_t tile_end,
-                    uint32_t *order_flag, bool by_ballot, bool test_violation);
-// Default: a tile's events are sorted in LDS (ranked by returning LDS atomics) and written run by run; the kernel checks the order
-// it produced and sets bit 0 of *order_flag if it is not the stable one -- the caller then redoes the batch with by_ballot (ranks
-// from ballots, stores in raster order; no flag).  test_violation: report a violation whatever the order (tests).
-// pix_of holds, per event slot, where the event's pixel is: plane * npix + i as 32 bits (launch_k_to_pixels writes k by pixel), or
-// -- in_tile_offsets, for launch_pack_g, whose workgroups know their tile -- i - tile * SORT_TILE as 16 bits in the same
-// buffer (launch_zero_padding then gets a null pix_of: the padding slots are never read).
-
-// Chains are padded to whole 64-event blocks: upper bounds of the slot / block counts of a pass.
-inline uint64_t max_event_slots(const Geometry &g) {
-    return (uint64_t)g.nplanes * g.npix + 64ull * g.nplanes * NCTX;
-}
-inline uint32_t max_event_blocks(const Geometry &g) { return (uint32_t)(max_event_slots(g) / 64); }
-
-// sorted_e needs max_event_slots() elements plus SORTED_PAD bytes (the spine reads 64 blocks ahead)
-constexpr size_t SORTED_PAD = 64 * 64 * 2 + 256;
-// k_map / plane buffers are read in whole 16-byte chunks by the tile staging
+// k_map / plane / slot buffers are read in whole 16-byte chunks by the tile staging
 constexpr size_t STAGE_PAD = 64;
-
-// resolve = spine (sequential per chain: state at every 64-event block) + assign (k of every event).
-// The spine is resumable: launched once per scatter slice with t_end = the slice's last tile + 1, it
-// advances every chain over the blocks whose events are already in place (chain_prog: 8 u32 per chain,
-// zeroed before the first launch).
-template <typename ET>
-void launch_zero_padding(hipStream_t s, ET *sorted_e, uint32_t *pix_of, const uint32_t *chain_base,
-                         const uint32_t *chain_len, const Geometry &g);
-
-// block_tag[b] = epoch << 5 | slice of the spine launch that resolved block b (4 bytes per 64-event block,
-// zero-initialised once; epoch in 1 .. 2^26 - 1, slice in 1..31).  partial = uint2[slices][chains]:
-// {block, events in place} of the chain's not-yet-full block after that slice (zeroed per sub-batch).
-template <typename ET>
-void launch_spine(hipStream_t s, const ET *sorted_e, uint32_t *block_state, const uint32_t *chain_base,
-                  const uint32_t *chain_len, const uint32_t *tile_off, uint32_t t_end, uint32_t *chain_prog,
-                  uint32_t *block_tag, uint32_t *partial, uint32_t epoch, uint32_t slice, const Geometry &g);
 
 // lengths / bit scan / pack work on a range [t0, t1) of every plane's PACK tiles, so they can follow the
 // spine slice by slice.  tile_bitoff is relative to the plane; plane_base (zero for gray, set by
@@ -213,27 +171,12 @@ struct PackTarget {
     uint8_t *scratch;
     uint64_t plane_slot;
 };
-// The single-pass pack with k gathered from chain order (k_pack_g) and the kernel that puts it there (k_assign_serial: one lane
-// replays one 64-event block, k_sorted[slot] = k of the event in that slot; launched per slice behind the spine like
-// the spine).  k_sorted needs max_event_slots() + STAGE_PAD bytes.
-template <typename ET>
-void launch_assign_serial(hipStream_t s, const ET *sorted_e, uint8_t *k_sorted, const uint32_t *block_state,
-                          const uint32_t *total_slots, const uint32_t *block_tag, const uint32_t *partial, uint32_t epoch,
-                          uint32_t slice, const Geometry &g);
-template <typename T>
-void launch_pack_g(hipStream_t s, const T *planes, const uint8_t *k_sorted, const uint32_t *pix_of, const uint32_t *tile_off,
-                   const uint32_t *chain_base, const uint32_t *chain_len, uint64_t *status, uint64_t *tile_bitoff,
-                   uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first, uint32_t *edge_last, uint32_t *error,
-                   const PackTarget &to, const Geometry &g, uint32_t st0, uint32_t st1, uint32_t epoch, uint32_t *ticket);
 // the single-pass pack on the tile-local layout: k gathered from the tile's own slots (kq / pix / tile_slots of TileLocal)
 template <typename T>
 void launch_pack_t(hipStream_t s, const T *planes, const uint8_t *kq, const uint16_t *pix, const uint32_t *tile_slots, uint32_t cap,
                    uint64_t *status, uint64_t *tile_bitoff, uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first,
                    uint32_t *edge_last, uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t st0, uint32_t st1, uint32_t epoch,
                    uint32_t *ticket);
-// two-pass pack: k from chain order (k_sorted) to a byte per pixel (k_map), all slots at once; pix_of = plane * npix + i
-void launch_k_to_pixels(hipStream_t s, const uint8_t *k_sorted, const uint32_t *pix_of, uint8_t *k_map, const uint32_t *total_slots,
-                         const Geometry &g);
 void launch_join_edges(hipStream_t s, const uint64_t *tile_bitoff, const uint32_t *tile_bits, const uint32_t *edge_first,
                        const uint32_t *edge_last, const PackTarget &to, const Geometry &g);
 void launch_concat_planes(hipStream_t s, const uint64_t *plane_base, const uint64_t *plane_carry, const PackTarget &to,

@@ -17,8 +17,7 @@ export TMPDIR=/tmp
 echo "[collect] bench line"
 timeout -k 10 400 python3 bench.py > "$O/bench.json" 2> "$O/bench.err" || { tail -5 "$O/bench.err"; exit 1; }
 cd /tmp
-# (The counter passes run blocking steps, the headline goes through the submission queue: on this workload both sort their events
-# with k_scatter -- felics_api.cpp, scatter_mode -- so the counters describe the kernels of the headline.)
+# (The counter passes run blocking steps, the headline goes through the submission queue: the same kernels on the same data.)
 PMC_ARGS="--steps 1 --warmup 0 --synchronous --no-blocking-extra --no-side-configs --no-decode-leg --cpu-seconds 0"
 echo "[collect] kernel trace"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 "$R/bench.py" --steps 10 --warmup 0 --cpu-seconds 0 --no-blocking-extra --no-side-configs --no-decode-leg > "$O/kt.log" 2>&1 || { tail -5 "$O/kt.log"; exit 1; }

@@ -68,8 +68,7 @@ def cheap_share(ctr):
 
 def main():
     lib = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "felics_amd", "_build", "libfelics.so"))
-    want = sys.argv[2:] or ["k_pack_g<unsigned char>", "k_scatter_ballot<unsigned char, unsigned char, true>", "k_scatter<unsigned char, unsigned char, true>", "k_spine2<unsigned char, 16", "k_hist<unsigned char>",
-                            "k_assign_serial<unsigned char>", "k_tile_offsets"]
+    want = sys.argv[2:] or ["k_pack_t<unsigned char>", "k_front<unsigned char, unsigned char>", "k_spine3<unsigned char>", "k_assign3<unsigned char>", "k_enum"]
     kernels = histograms(lib)
     print("# static opcode histograms of %s" % os.path.relpath(lib, ROOT))
     print("# class: C = 1.0 ns, E = 1.7 ns per wave64 instruction and SIMD (profiles/r04/valu_rate.txt); S scalar, L LDS, M vector memory")

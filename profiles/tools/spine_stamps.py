@@ -1,13 +1,14 @@
-"""Where the walker of the longest chain (context 1 of plane 0 of an S1 frame) spends its time, phase by phase.
+"""Where the two waves of the longest chain's spine workgroup (context 1 of plane 0 of an S1 frame: k_spine3's walker and
+helper) spend their time.
 
 Needs a library built with the stamps compiled in (they are not in the product build):
-    make -C felics_amd/csrc lib OUT=../../scratch/sstamps CXXFLAGS="-O3 -std=c++17 -fPIC -DFELICS_SPINE_STAMPS"
+    profiles/tools/variant.sh sstamps -DFELICS_SPINE_STAMPS
     python profiles/tools/spine_stamps.py [frames]        # on the GPU box, from the repository root
 """
 import os, sys, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("FELICS_LIB_PATH", os.path.join(ROOT, "scratch", "sstamps", "libfelics.so"))
+os.environ.setdefault("FELICS_LIB_PATH", os.path.join(ROOT, "felics_amd", "_variants", "sstamps", "libfelics.so"))
 os.environ.setdefault("FELICS_SLICES", "1")
 import numpy as np, torch
 import felics_amd
@@ -31,10 +32,10 @@ for _ in range(R):
 dt = (time.time() - t) / R
 lib.felics_debug_spine_stamps(buf, 0)
 v = [x / R for x in buf]
-names = ["waiting at the batch barrier", "block steps without a halving", "prefix reads + first threshold round", "halving update + further rounds"]
-halv, blocks, batches, total = v[4], v[5], v[6], v[7]
-print("%d frame(s), blocking call %.3f ms; walker of chain (plane 0, context 1): %.0f halvings, %.0f blocks, %.0f hand-overs, %.0f ticks (shader cycles; the stamps themselves cost about as much as a block step)" % (n, dt * 1e3, halv, blocks, batches, total))
-for i, nm in enumerate(names):
-    print("  %-40s %10.0f ticks  %5.1f %%  %7.1f per halving" % (nm, v[i], 100.0 * v[i] / total, v[i] / halv))
-print("  %-40s %10.0f ticks per halving" % ("total", total / halv))
+win, total = v[5], v[7]
+print("%d frame(s), blocking call %.3f ms; chain (plane 0, context 1): %.0f windows of 64 records, walker's life %.0f ticks (shader cycles) = %.0f per window"
+      % (n, dt * 1e3, win, total, total / max(win, 1)))
+for i, nm in enumerate(["walker: waiting at the hand-over barrier", "walker: walking", "helper: finishing + producing windows", "helper: waiting at the barrier"]):
+    print("  %-42s %10.0f ticks  %5.1f %%  %7.1f per window" % (nm, v[i], 100.0 * v[i] / total, v[i] / max(win, 1)))
+print("  halvings walked by all chains of the call: %.0f" % v[6])
 enc.close()

@@ -3,11 +3,12 @@
 traffic.json: per kernel, per step (64 S1 4K gray frames): FETCH_SIZE and WRITE_SIZE (KB counters x 1024), the
 correction MI355X_MICROARCH.md (HBM) prescribes, and the SQ instruction counters.
   * FETCH_SIZE reads exactly half the bytes of wide (16 B per lane) coalesced loads on gfx950.  Kernels whose reads are such
-    loads get fetch x 2 ("x2: uint4 loads").  k_hist and k_scatter read the input with unaligned 4- / 8-byte loads per lane,
-    several trips in flight (since round 3): the counter under-reports those too -- k_hist, whose only reads are the 530.8 MB of
-    input, reports ~ 334 MB.  Their rule is "calibrated": raw x (input bytes / k_hist's raw count), the factor taken from this very
-    run (k_hist reads every pixel exactly once, so it cannot have fetched less than the input).  k_pack_g reads its pixels with
-    16-byte loads per lane (counted at half) next to byte / word / dword reads of k, offsets and the run table: raw + the input size.
+    loads get fetch x 2 ("x2: uint4 loads").  k_front reads the input with unaligned 4- / 8-byte loads per lane, several trips
+    in flight: the counter under-reports those too (round 4's k_hist, whose only reads were the 530.8 MB of input, reported
+    ~ 334 MB).  k_front reads nothing but the input from HBM -- every pixel once, the row above it from cache -- so its fetch
+    is taken as max(raw, input bytes) ("input: ..."), the factor input / raw kept as _fetch_calibration_factor.  k_pack_t reads
+    its pixels with 16-byte loads per lane (counted at half) next to dword / 8-byte reads of k and pixel offsets: raw + the
+    input size.
   * WRITE_SIZE is exact for full-line stores; partial-line stores (scatter) count the written sectors.
 """
 import collections
@@ -50,19 +51,17 @@ for kind in ("fetch", "write", "sq", "sq2"):
 
 # which FETCH_SIZE rule applies to which kernel (see the module docstring)
 INPUT_BYTES = 64 * 3840 * 2160
-X2 = {"k_spine": "x2: uint4 loads of the event blocks",
+X2 = {"k_spine3": "x2: uint4 loads of the records' events (the 8-byte descriptors are a tenth of them)",
       "k_pack": "x2: uint4 staging", "k_lengths": "x2: uint4 staging", "k_concat_planes": "x1",
-      "k_pack_g": "raw + input bytes: the 16-byte loads of the pixels (twice the input size: the group and the row above it, counted at half) are its only wide loads; k, offsets and the run table are read as bytes / words / dwords",
-      "k_assign_serial": "x2: uint4 loads of the events and the block states",
-      "k_hist": "calibrated: raw x (input bytes / k_hist raw): the kernel reads the input exactly once",
-      "k_scatter": "calibrated: raw x (input bytes / k_hist raw): the same unaligned 4-byte loads as k_hist",
-      "k_scatter_ballot": "calibrated: raw x (input bytes / k_hist raw): the same unaligned 4-byte loads as k_hist"}
+      "k_pack_t": "raw + input bytes: the 16-byte loads of the pixels (twice the input size: the group and the row above it, counted at half) are its only wide loads; k and pixel offsets are read as dwords / 8 bytes",
+      "k_assign3": "x2: uint4 loads of the records' states and events",
+      "k_front": "input: max(raw, input bytes): the kernel reads every pixel exactly once (unaligned 4-byte loads, counted low) and nothing else"}
 res = {}
 total = 0
 valu_total = 0
 valu_weighted_ns = 0.0
-hist_raw = counters.get("k_hist", {}).get("FETCH_SIZE", 0.0) * 1024
-calib = INPUT_BYTES / hist_raw if hist_raw else 1.0
+front_raw = counters.get("k_front", {}).get("FETCH_SIZE", 0.0) * 1024
+calib = INPUT_BYTES / front_raw if front_raw else 1.0
 try:  # each kernel's share of 1.0 ns instructions, from the library this run used (profiles/tools/opcodes.py)
     import opcodes
     from felics_amd import build as fbuild_
@@ -80,8 +79,8 @@ for k, c in sorted(counters.items()):
     write = c.get("WRITE_SIZE", 0.0) * 1024
     rule = X2.get(k, "x1: dword-or-narrower loads per lane")
     fetch_c = fetch * (2 if rule.startswith("x2") else 1)
-    if rule.startswith("calibrated"):
-        fetch_c = fetch * calib
+    if rule.startswith("input"):
+        fetch_c = max(fetch, INPUT_BYTES)
     if rule.startswith("raw + input bytes"):
         fetch_c = fetch + INPUT_BYTES  # two spans of the input's size read with 16-byte loads, each counted at half
     e = {"fetch_bytes_raw": int(fetch), "fetch_rule": rule, "fetch_bytes_per_step": int(fetch_c), "write_bytes_per_step": int(write),

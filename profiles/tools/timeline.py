@@ -3,8 +3,13 @@ f=glob.glob(sys.argv[1]+'/*/*kernel_trace.csv')[0]
 rows=[r for r in csv.DictReader(open(f)) if 'felics' in r['Kernel_Name']]
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 nl=int(sys.argv[2]) if len(sys.argv)>2 else 2
-idx=[i for i,r in enumerate(rows) if 'k_hist' in r['Kernel_Name']] or [i for i,r in enumerate(rows) if 'k_wide_count' in r['Kernel_Name']]
-start=idx[-nl]
+# the first kernel of a sub-batch: k_front's first slice (four slices per queued submission), k_wide_count for 16-bit samples
+idx=[i for i,r in enumerate(rows) if 'k_front' in r['Kernel_Name']]
+per=4
+if not idx:
+    idx=[i for i,r in enumerate(rows) if 'k_wide_count' in r['Kernel_Name']]
+    per=1
+start=idx[-nl*per]
 last=rows[start:]
 base=int(last[0]['Start_Timestamp'])
 for r in last:

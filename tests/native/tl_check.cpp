@@ -166,7 +166,8 @@ static int run_case(const char *name, const std::vector<T> &planes_h, uint32_t W
             for (uint32_t c = 0; c < NC; c++) {
                 start[t][c] = ps;
                 const uint32_t want = (ps / REC) | (cnt[t][c] << 16);
-                if (runtab[pt * NC + c] != want) fail("runtab", pt, c, runtab[pt * NC + c], want);
+                const size_t ri = ((size_t)pl * NC + c) * g.sort_tiles + t;
+                if (runtab[ri] != want) fail("runtab", pt, c, runtab[ri], want);
                 ps += (cnt[t][c] + REC - 1) / REC * REC;
             }
             if (tslots[pt] != ps) fail("tile_slots", pt, 0, tslots[pt], ps);

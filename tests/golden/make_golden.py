@@ -36,6 +36,16 @@ COPY = [
     # PlanarConfiguration tag, 16-bit gray of odd size (1081 x 1081) in 3 strips
     "rgb/8bit/mandril_color.tif", "grayscale/16bit/heightmap.tiff",
 ]
+# Originals of the reference's integration corpus at full size (tests/compress.rs:73-103 round-trips all of image-suite/): the
+# four 1024 x 1024 gray8 files, two >= 1000 x 1000 gray16 ones, three 1024 x 1024 RGB8 ones, the little-endian multi-strip
+# 512 x 512 RGB8 file, and a 512 x 512 file of each kind -> tests/golden/suite/ (data; tests/test_gpu_parity.py encodes each on
+# the GPU, singly and in same-shape batches of mixed content)
+SUITE_COPY = [
+    "grayscale/8bit/3.2.25.tiff", "grayscale/8bit/5.3.01.tiff", "grayscale/8bit/5.3.02.tiff", "grayscale/8bit/7.2.01.tiff",
+    "grayscale/16bit/bands.tiff", "grayscale/16bit/octagon.tiff",
+    "rgb/8bit/2.2.01.tiff", "rgb/8bit/2.2.02.tiff", "rgb/8bit/2.2.03.tiff", "rgb/8bit/lena_color_512.tif",
+    "grayscale/8bit/5.2.08.tiff", "grayscale/16bit/boat.tiff", "rgb/8bit/2.1.01.tiff",
+]
 DOC_SIZE_PINS = {"house.tiff": 105741, "tree.tiff": 122246, "lena_color_256.tif": 110707, "mandril_color.tif": 617524}
 
 
@@ -53,6 +63,20 @@ def main():
             f.write(data)
         pins["files"][name] = {"shape": list(img.shape), "dtype": str(img.dtype), "size": len(data),
                                "sha256": hashlib.sha256(data).hexdigest()}
+    os.makedirs(os.path.join(HERE, "suite"), exist_ok=True)
+    pins["suite"] = {}
+    for rel in SUITE_COPY:
+        name = os.path.basename(rel)
+        dst = os.path.join(HERE, "suite", name)
+        shutil.copyfile(os.path.join(SUITE, rel), dst)
+        os.chmod(dst, 0o644)
+        img = np.array(Image.open(dst))
+        data = o.compress(img)
+        assert (o.decompress(data) == img).all(), name
+        with open(dst + ".felics", "wb") as f:
+            f.write(data)
+        pins["suite"][name] = {"shape": list(img.shape), "dtype": str(img.dtype), "size": len(data),
+                               "sha256": hashlib.sha256(data).hexdigest(), "from": "image-suite/" + rel}
     # hand-derived vector of SURVEY.md §8(c) (derived by reading the reference, not by running it)
     pins["hand_vector"] = {
         "pixels": [[10, 12, 11], [13, 9, 12]],
@@ -72,7 +96,7 @@ def main():
         pins["synthetic"]["gray16_%dx%d" % (w, h)] = {"size": len(data), "sha256": hashlib.sha256(data).hexdigest()}
     with open(os.path.join(HERE, "pins.json"), "w") as f:
         json.dump(pins, f, indent=1, sort_keys=True)
-    print("wrote", len(pins["files"]), "fixtures")
+    print("wrote", len(pins["files"]), "fixtures and", len(pins["suite"]), "full-size suite originals")
 
 
 if __name__ == "__main__":

@@ -832,6 +832,39 @@ def test_natural_image_mosaics(enc, oracle):
         assert (felics_amd.decompress_image(io.BytesIO(got[i])) == crops[i]).all(), i
 
 
+def test_suite_originals_full_size(enc, oracle):
+    """Originals of the reference's integration corpus at full size through the HIP encoder (tests/compress.rs:73-103 round-trips
+    every file of image-suite/): the four 1024 x 1024 gray8 files, gray16 at 1000 x 1000 and 1024 x 1024, three 1024 x 1024 RGB8
+    files, the little-endian multi-strip 512 x 512 RGB8 file and a 512 x 512 file of each kind (tests/golden/suite/, data;
+    make_golden.py).  Each is encoded singly and compared with the committed oracle stream and its pinned sha256; the files of
+    one shape then go through ONE batch call (mixed content side by side in one submission); everything is decoded back."""
+    import felics_amd
+    from PIL import Image
+
+    pins = json.load(open(os.path.join(GOLDEN, "pins.json")))["suite"]
+    assert len(pins) >= 13
+    imgs, want = {}, {}
+    for name, meta in sorted(pins.items()):
+        path = os.path.join(GOLDEN, "suite", name)
+        img = np.array(Image.open(path))
+        assert list(img.shape) == meta["shape"] and str(img.dtype) == meta["dtype"], name
+        imgs[name] = np.ascontiguousarray(img)
+        want[name] = open(path + ".felics", "rb").read()
+        assert hashlib.sha256(want[name]).hexdigest() == meta["sha256"] and len(want[name]) == meta["size"], name
+        got = enc.compress(imgs[name])
+        assert got == want[name], name
+        assert (felics_amd.decompress_image(io.BytesIO(got)) == imgs[name]).all(), name
+    groups = {}
+    for name, img in imgs.items():
+        groups.setdefault((img.shape, str(img.dtype)), []).append(name)
+    assert max(len(v) for v in groups.values()) >= 4  # the 1024 x 1024 gray8 files in one call
+    for key, names in groups.items():
+        if len(names) > 1:
+            got = enc.compress_batch([imgs[n] for n in names] + [imgs[names[0]][::-1].copy()])
+            assert got[:-1] == [want[n] for n in names], key
+            assert got[-1] == oracle.compress(imgs[names[0]][::-1].copy()), key
+
+
 def test_many_tiny_sixteen_bit_frames(enc, oracle):
     """A batch of 70 000 tiny 16-bit frames: the 16-bit path takes at most 2^16 planes per pass (its front end scans tiles x
     planes counts in one workgroup), so this batch goes through two passes; a sample is compared with the oracle and decoded back."""

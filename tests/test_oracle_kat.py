@@ -89,6 +89,22 @@ def test_phasein_encoding(oracle):
     assert oracle.phasein_text(7, 0) == "101"
 
 
+def test_phasein_doc_table_n27(oracle):
+    """DOC.md:111-124: the author's worked example, the code table of the integers of [0, 27) -- m = 4, five 4-bit codewords
+    for the integers 0..4, 5-bit ones for 5..26 -- printed in the mock's order (m-bit field LSB first, then the extra bit) and
+    BEFORE the rotation that `encode` applies to its input (phase_in_coding.rs:45-47, :59-84: value v is coded as the integer
+    r = v + 2^m mod n).  So the table's row r is what the coder emits for the value (r - 16) mod 27.  (The table prints
+    integer 21 twice; the second is 22.)"""
+    table = ["0000", "1000", "0100", "1100", "0010", "10100", "10101", "01100", "01101", "11100",
+             "11101", "00010", "00011", "10010", "10011", "01010", "01011", "11010", "11011", "00110",
+             "00111", "10110", "10111", "01110", "01111", "11110", "11111"]
+    assert oracle.phasein_params(27) == (4, 11, 5)  # m, left_p = n - 2^m (DOC.md's |A| = 22 long codewords = 2 left_p), right_p = |B| = 2^(m+1) - n short ones
+    for r, want in enumerate(table):
+        assert oracle.phasein_text(27, (r - 16) % 27, mock=True) == want, r
+    assert len(set(table)) == 27  # a prefix code: no codeword twice (and, below, none a prefix of another)
+    assert not any(a != b and b.startswith(a) for a in table for b in table)
+
+
 def test_phasein_closed_form(oracle):
     """r = v + 2^m (mod n); short r in m bits, long r + right_p in m+1 bits."""
     for n in range(1, 600):

@@ -295,6 +295,34 @@ def main():
                           "frac_of_hbm_peak_queued": round(npix * ch / queued / 1e9 / HBM_PEAK_GBS, 5),
                           "calls": reps, "byte_compared_with_oracle": True}
 
+    # End to end with HOST buffers, the reference's own call shape (compress(&self, W): compression.rs:255-282; SURVEY.md section 8(d)
+    # asks for this figure next to the HBM-resident one; it is never `value`): the 64 frames in page-locked host memory in, the 64
+    # streams in page-locked host memory out, through felics_compress_batch -- chunks on the submission queue, frames going in and
+    # streams coming back on copy streams of their own under the kernels.
+    if side is not None:
+        h_in = frames.cpu().pin_memory()
+        slot_h = int(npix * 1.25) + 4096
+        h_out = torch.empty((F, slot_h), dtype=torch.uint8).pin_memory()
+        in_ptrs = [h_in[i].data_ptr() for i in range(F)]
+        out_ptrs = [h_out[i].data_ptr() for i in range(F)]
+        lens_h = enc.compress_batch_host(in_ptrs, F, W, H, 0, 0, out_ptrs, [slot_h] * F)  # (also sizes the staging buffers)
+        for i in (0, 1, F - 1):
+            if h_out[i][: int(lens_h[i])].numpy().tobytes() != oracle.compress(h_in[i].numpy()):
+                raise SystemExit("end-to-end leg: stream %d differs from the oracle" % i)
+        reps_h = 5
+        t1 = time.perf_counter()
+        for _ in range(reps_h):
+            lens_h = enc.compress_batch_host(in_ptrs, F, W, H, 0, 0, out_ptrs, [slot_h] * F)
+        e2e = (time.perf_counter() - t1) / reps_h
+        out_bytes = int(lens_h.sum())
+        side["end_to_end_host_64_frames"] = {
+            "ms_per_batch": round(e2e * 1e3, 3), "MPix_s": round(F * npix / e2e / 1e6, 1),
+            "h2d_GBs": round(F * npix / e2e / 1e9, 2), "d2h_GBs": round(out_bytes / e2e / 1e9, 2),
+            "note": "felics_compress_batch: %d frames from page-locked host memory, %d stream bytes back to page-locked host memory; "
+                    "the link carries %.0f MB in and %.0f MB out per batch (PCIe-inclusive: never `value`)" % (F, out_bytes, F * npix / 1e6, out_bytes / 1e6),
+            "streams_byte_compared_with_oracle": 3}
+        del h_in, h_out
+
     # Config 5's per-GPU share (64 4K RGB8 frames per submission) rides along too: three steps through the queue.
     if side is not None:
         F5 = 64
@@ -332,11 +360,15 @@ def main():
         F16 = 16
         base16 = [torch.from_numpy(synth.gray16(W, H, first_frame + i).view(np.int16)) for i in range(4)]
         fr16 = torch.stack([base16[i % 4] for i in range(F16)]).to(dev)
+        prev_lanes = os.environ.get("FELICS_LANES")  # (the user's, or --lanes': put back afterwards)
         os.environ["FELICS_LANES"] = "4"
         try:
             enc16 = felics_amd.Encoder(local)
         finally:
-            del os.environ["FELICS_LANES"]
+            if prev_lanes is None:
+                del os.environ["FELICS_LANES"]
+            else:
+                os.environ["FELICS_LANES"] = prev_lanes
         q16 = enc16.lane_count()
         outs16 = [torch.empty(int(F16 * npix * 2 * 1.25) + (1 << 20), dtype=torch.uint8, device=dev) for _ in range(q16)]
         o16, l16 = enc16.compress_batch_device(fr16.data_ptr(), F16, W, H, 0, 1, outs16[0].data_ptr(), outs16[0].numel())
@@ -413,7 +445,7 @@ def main():
             del d_big
             big = {"streams": NB, "gpu_MPix_s": round(NB * npix / big_s / 1e6, 1), "gpu_seconds_per_batch": round(big_s, 3),
                    "MPix_s_per_stream": round(npix / big_s / 1e6, 3), "form": "64 streams per wave (lane = stream)"}
-        except torch.OutOfMemoryError:
+        except (torch.OutOfMemoryError, felics_amd.FelicsError):  # no room for 34 GB of frames (or for the library's tables): no large-batch figure
             big = None
         decode = {"gpu_MPix_s": round(F * npix / gpu_s / 1e6, 1), "gpu_seconds_per_batch": round(gpu_s, 3), "streams": F,
                   "gpu_note": "felics_decompress_batch_device: one wave per stream, %d streams = %d waves on 256 CUs" % (F, F),

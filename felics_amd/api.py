@@ -234,6 +234,21 @@ class Encoder:
                 self._raise(rc)
             return [outs[i][: lens[i]].tobytes() for i in range(n)]
 
+    def compress_batch_host(self, pixel_ptrs, n, w, h, color, depth, out_ptrs, caps):
+        """felics_compress_batch on raw HOST pointers (lists of n addresses: frames in, buffers of caps[i] bytes out): the
+        reference's call shape without Python objects in the way -- the copies run at the link's rate when the memory behind the
+        pointers is page-locked (a pinned torch tensor).  Returns the streams' lengths (numpy)."""
+        px = (C.c_void_p * n)(*[int(p) for p in pixel_ptrs])
+        op = (C.c_void_p * n)(*[int(p) for p in out_ptrs])
+        cp = (C.c_size_t * n)(*[int(c) for c in caps])
+        lens = (C.c_size_t * n)()
+        rc = lib().felics_compress_batch(self._h, n, px, w, h, int(color), int(depth), op, cp, lens)
+        if rc == -8:
+            raise FelicsError(rc, "a stream needs up to %d bytes" % max(lens))
+        if rc != 0:
+            self._raise(rc)
+        return np.array(lens[:], dtype=np.uint64)
+
     def compress_batch_device(self, d_pixels, n, w, h, color, depth, d_out, d_out_cap):
         """Frames and streams in device memory (raw pointers). Returns (offsets, lens) numpy arrays."""
         offs = np.zeros(n, dtype=np.uint64)

@@ -98,7 +98,7 @@ struct felics_ctx {
     // spine closely.  With two submissions in flight the other batch keeps the GPU busy, and every slice costs
     // a launch and a hand-over per stage: few slices are faster there (measured: 12 -> 5.3, 6 -> 5.1, 3 -> 4.8 ms).
     int slices_blocking = 6;    // FELICS_SLICES
-    int slices_queued = 4;      // (round 3 measured 2-4 lanes x 1-6 slices within 3 % of each other: profiles/r03/experiments.txt;
+    int slices_queued = 2;      // (round 5, tile-local pipeline: 1 slice 3.05, 2 2.54, 3 2.90, 4 2.86, 6 2.82 ms per step with two lanes; round 3 measured 2-4 lanes x 1-6 slices within 3 % of each other: profiles/r03/experiments.txt;
                                 // round 4, with k_scatter: 2 slices 2.94, 3 2.82-2.89, 4 2.78-2.80, 6 2.89-2.91, 8 2.96 ms; three lanes 3.06)
     // k_pack_g takes its tiles from the workgroup index while the lanes share the tail stream: one pack kernel then has the
     // look-back to itself.  With a tail stream per lane (FELICS_OWN_TAILS=1), and after a look-back has given up once, tiles are
@@ -135,6 +135,9 @@ struct felics_ctx {
     float span_ms = 0.f;        // profiling: first kernel -> sizes on the host, of the last submission collected
     int stage_launches[ST_COUNT] = {};
     DevBuf in, out;  // staging of the host-pointer entry points
+    hipStream_t copy_in = nullptr, copy_out = nullptr;  // felics_compress_batch: frames to the device / streams back, beside the kernels
+    hipEvent_t h2d_done[MAX_LANES] = {};                // a chunk's frames have arrived (one per lane)
+    hipEvent_t wait_before_submit = nullptr;            // the next sub-batch's first kernel waits for this event (set around one submit)
     DevBuf dec_meta, dec_planes;  // GPU decoder: offsets | lens | status of a batch; Y / Co / Cg planes of RGB streams
     DevBuf dec_lane_table;        // gray streams decoded 64 to a wave: the estimator rows that do not fit in LDS (3 KB per stream, zeroed per call)
     DevBuf dec_table;             // 16-bit streams: estimator tables in HBM (8.4 MB per stream of a pass), zeroed once, rows tagged with an epoch
@@ -632,6 +635,8 @@ int launch_sub_batch(felics_ctx *ctx, Lane &l, size_t first, size_t cnt, const v
     l.first_image = first;
     const uint8_t *src = (const uint8_t *)d_pixels + first * frame_bytes;
     l.d_planes = src;
+    if (ctx->wait_before_submit)  // (felics_compress_batch: the frames are still on their way)
+        HIP_TRY(ctx, hipStreamWaitEvent(wide || ctx->serial ? l.stream : l.front, ctx->wait_before_submit, 0));
     if (ctx->profiling)  // on the stream the sub-batch's first kernel runs on
         HIP_TRY(ctx, hipEventRecord(l.span_begin, wide || ctx->serial ? l.stream : l.front));
     if (planes == 3) {
@@ -904,6 +909,13 @@ int felics_ctx_create(int device, felics_ctx **out) {
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);  // numerically: low >= high
     int prio_spine = prio_high, prio_front = prio_low, prio_tail = prio_high;
+    if (const char *e = getenv("FELICS_EXP_PRIO")) {  // (tuning experiments: three digits, 1 = high, for spine / front / tail)
+        if (strlen(e) >= 3) {
+            prio_spine = e[0] == '1' ? prio_high : prio_low;
+            prio_front = e[1] == '1' ? prio_high : prio_low;
+            prio_tail = e[2] == '1' ? prio_high : prio_low;
+        }
+    }
     for (int li = 0; li < ctx->nlanes; li++) {
         Lane &l = ctx->lanes[li];
         ok = ok && hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio_spine) == hipSuccess;
@@ -973,6 +985,10 @@ void felics_ctx_destroy(felics_ctx *ctx) {
         if (l.stream) (void)hipStreamDestroy(l.stream);
         if (l.tail && (&l == &ctx->lanes[0] || l.tail != ctx->lanes[0].tail)) (void)hipStreamDestroy(l.tail);
     }
+    if (ctx->copy_in) (void)hipStreamSynchronize(ctx->copy_in), (void)hipStreamDestroy(ctx->copy_in);
+    if (ctx->copy_out) (void)hipStreamSynchronize(ctx->copy_out), (void)hipStreamDestroy(ctx->copy_out);
+    for (hipEvent_t ev : ctx->h2d_done)
+        if (ev) (void)hipEventDestroy(ev);
     release(ctx->in);
     release(ctx->out);
     release(ctx->dec_meta);
@@ -1088,6 +1104,12 @@ int felics_wait_batch(felics_ctx *ctx, int ticket, uint64_t *offsets, uint64_t *
                          nullptr, o.overflow && !o.redo());
 }
 
+// The reference's own call shape: images in host memory in, .felics bytes in host memory out (compression.rs:255-282, :322-371;
+// cfelics.rs:24-31).  The batch goes through the submission queue in CHUNKS: the frames of chunk c + 1 are copied to the device
+// on a copy stream of its own while chunk c is encoded and the streams of chunk c - 1 are copied back on a third stream, so the
+// link is busy in both directions under the kernels.  (The copies are hipMemcpyAsync from / to the caller's pointers: at the
+// link's rate, and asynchronous, if that memory is page-locked -- hipHostMalloc, hipHostRegister, a pinned torch tensor -- and
+// through the runtime's staging otherwise.)
 int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, uint32_t w, uint32_t h, int color,
                           int depth, uint8_t *const *outs, const size_t *caps, size_t *lens) {
     if (!ctx || (n && (!pixels || !outs || !caps || !lens))) return FELICS_E_INVALID_ARGUMENT;
@@ -1098,35 +1120,76 @@ int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, 
     if (any_pending(ctx)) return FELICS_E_INVALID_ARGUMENT;  // felics_wait_batch first
     const uint32_t planes = color == FELICS_COLOR_RGB ? 3 : 1;
     const size_t frame_bytes = (size_t)w * h * planes * (depth == FELICS_DEPTH_16 ? 2 : 1);
+    for (size_t i = 0; i < n && frame_bytes; i++)
+        if (!pixels[i]) return FELICS_E_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy_in) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking));
+        for (int i = 0; i < MAX_LANES; i++) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->h2d_done[i], hipEventDisableTiming));
+    }
     const size_t per_pass = max_images_per_pass((uint64_t)w * h, planes, depth);
-    std::vector<uint64_t> offs, sizes;
+    // chunks: eight per batch (the first chunk's way in and the last one's way out are what the kernels cannot cover), none larger
+    // than a pass; a stream's slot as encode_device sizes it
+    const size_t chunk = std::max<size_t>(1, std::min(per_pass, (n + 7) / 8));
+    const uint64_t slot = ((uint64_t)frame_bytes + frame_bytes / 4 + 64 + 15) & ~15ull;
+    if ((rc = reserve(ctx, ctx->in, frame_bytes * n + 64)) != 0) return rc;
+    if ((rc = reserve(ctx, ctx->out, (size_t)(slot * n) + 64)) != 0) return rc;
+    struct Flying {
+        int ticket;
+        size_t first, cnt;
+    };
+    std::vector<Flying> flying;
+    std::vector<uint64_t> offs(chunk), sizes(chunk);
     int result = FELICS_OK;
-    for (size_t first = 0; first < n; first += per_pass) {
-        const size_t cnt = std::min(per_pass, n - first);
-        if ((rc = reserve(ctx, ctx->in, frame_bytes * cnt)) != 0) return rc;
-        for (size_t i = 0; i < cnt && frame_bytes; i++) {
-            if (!pixels[first + i]) return FELICS_E_INVALID_ARGUMENT;
-            HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)ctx->in.p + i * frame_bytes, pixels[first + i], frame_bytes,
-                                        hipMemcpyHostToDevice, ctx->lanes[0].stream));
-        }
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->lanes[0].stream));  // the other lanes read ctx->in too
-        offs.assign(cnt, 0);
-        sizes.assign(cnt, 0);
-        uint8_t *d_out = nullptr;
-        rc = encode_device(ctx, ctx->lanes[0], cnt, ctx->in.p, w, h, color, depth, nullptr, 0, offs.data(), sizes.data(), &d_out);
-        if (rc) return rc;
-        for (size_t i = 0; i < cnt; i++) {
-            lens[first + i] = (size_t)sizes[i];
-            if (sizes[i] > caps[first + i] || !outs[first + i]) {
+    auto land = [&](const Flying &f) -> int {  // wait for a chunk and start its streams on their way to the caller
+        int r = felics_wait_batch(ctx, f.ticket, offs.data(), sizes.data());
+        if (r) return r;
+        for (size_t i = 0; i < f.cnt; i++) {
+            lens[f.first + i] = (size_t)sizes[i];
+            if (sizes[i] > caps[f.first + i] || !outs[f.first + i]) {
                 result = FELICS_E_BUFFER_TOO_SMALL;  // lens[] still reports every size needed
                 continue;
             }
-            HIP_TRY(ctx, hipMemcpyAsync(outs[first + i], d_out + offs[i], (size_t)sizes[i], hipMemcpyDeviceToHost,
-                                        ctx->lanes[0].stream));
+            HIP_TRY(ctx, hipMemcpyAsync(outs[f.first + i], (uint8_t *)ctx->out.p + f.first * slot + offs[i], (size_t)sizes[i],
+                                        hipMemcpyDeviceToHost, ctx->copy_out));
         }
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->lanes[0].stream));
+        return FELICS_OK;
+    };
+    auto drain = [&](int r) {  // an error: nothing of this context may be left in flight behind the caller's back
+        for (const Flying &f : flying) (void)felics_wait_batch(ctx, f.ticket, offs.data(), sizes.data());
+        (void)hipStreamSynchronize(ctx->copy_in);
+        (void)hipStreamSynchronize(ctx->copy_out);
+        return r;
+    };
+    for (size_t first = 0; first < n; first += chunk) {
+        const size_t cnt = std::min(chunk, n - first);
+        for (size_t i = 0; i < cnt && frame_bytes; i++) {
+            const hipError_t e = hipMemcpyAsync((uint8_t *)ctx->in.p + (first + i) * frame_bytes, pixels[first + i], frame_bytes,
+                                                hipMemcpyHostToDevice, ctx->copy_in);
+            if (e != hipSuccess) return drain(hip_fail(ctx, e, "copying frames to the device"));
+        }
+        if ((int)flying.size() == ctx->nlanes) {  // every lane is busy: the oldest chunk first
+            rc = land(flying.front());
+            flying.erase(flying.begin());
+            if (rc) return drain(rc);
+        }
+        hipEvent_t ev = ctx->h2d_done[ctx->next_lane];
+        if (hipEventRecord(ev, ctx->copy_in) != hipSuccess) return drain(hip_fail(ctx, hipGetLastError(), "hipEventRecord"));
+        ctx->wait_before_submit = ev;  // the chunk's first kernel waits for its frames (launch_sub_batch)
+        int ticket = -1;
+        rc = felics_submit_batch_device(ctx, cnt, (const uint8_t *)ctx->in.p + first * frame_bytes, w, h, color, depth,
+                                        (uint8_t *)ctx->out.p + first * slot, (size_t)(slot * cnt), &ticket);
+        ctx->wait_before_submit = nullptr;
+        if (rc) return drain(rc);
+        flying.push_back(Flying{ticket, first, cnt});
     }
+    while (!flying.empty()) {
+        rc = land(flying.front());
+        flying.erase(flying.begin());
+        if (rc) return drain(rc);
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_out));
     return result;
 }
 

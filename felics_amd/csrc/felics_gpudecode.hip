@@ -462,7 +462,7 @@ __global__ __launch_bounds__(64) void k_decode8_lanes(const uint8_t *__restrict_
             br.refill();  // >= 33 valid bits: both kinds of code are read off the top 32 of them, then consumed in one go
             const uint32_t top = (uint32_t)(br.acc >> 32);
             const bool in_range = (top >> 31) != 0;
-            // -- in range: `1`, then the phased-in code of p - L in m or m + 1 bits (phase_in_coding.rs:86-112), m <= 7
+            // -- in range: `1`, then the phased-in code of p - L in m or m + 1 bits (phase_in_coding.rs:86-112), m <= 8 (context 255: n = 256)
             const uint32_t nn = ctx + 1;
             const uint32_t m = 31u - (uint32_t)__builtin_clz(nn);
             const uint32_t right_p = (2u << m) - nn, left_p = nn - (1u << m);

@@ -83,6 +83,60 @@ __global__ __launch_bounds__(256) void k_rgb8_to_planes(const uint8_t *__restric
     }
 }
 
+// ---- Instruction forms.  profiles/r04/valu_rate.txt: a gfx950 SIMD issues 32-bit add / sub / and / or / xor / lshr / ashr,
+// v_bitop3_b32 and every 16-bit VOP2 instruction (min, max, add, shifts) in 1.0 ns, everything else -- v_min_u32,
+// v_lshlrev_b32, v_cndmask, compares, v_bfe, SDWA / DPP / VOP3 forms, 64-bit shifts -- in 1.7 ns.  The compiler prices them
+// alike and turns sign masks back into compare + select, so the code builder names the cheap forms itself.
+template <uint32_t TABLE>
+__device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TABLE);  // bit i of the result = TABLE[a_i << 2 | b_i << 1 | c_i]
+}
+constexpr uint32_t BT_SEL = 0xE4;      // c ? a : b  =  (a & c) | (b & ~c)
+constexpr uint32_t BT_OR_ANDN = 0xF4;  // a | (b & ~c)
+constexpr uint32_t BT_ANDN = 0x30;     // a & ~b
+__device__ __forceinline__ uint32_t min_u16(uint32_t a, uint32_t b) {  // operands < 2^16
+    uint32_t r;
+    asm("v_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t max_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t twice(uint32_t a) {  // a + a as an add (the compiler would make it a left shift)
+    uint32_t r;
+    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ uint32_t vgpr_const(uint32_t v) {  // a constant kept in a vector register: the shifted operand of v_lshrrev_b32_e32
+    uint32_t r;
+    asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
+    return r;
+}
+
+// Sample j of a group held in packed registers, as an unsigned 16-bit value in an order-preserving offset: u8 samples as
+// they are, i16 samples (Y / Co / Cg planes) with the sign bit flipped -- the codes depend on differences only.
+__device__ __forceinline__ uint32_t field_at(const uint32_t *w, uint32_t j, uint8_t) {
+    const uint32_t x = w[j >> 2];
+    switch (j & 3u) {
+        case 0: return x & 0xFFu;
+        case 1: {
+            uint32_t r;
+            asm("v_lshrrev_b16 %0, 8, %1" : "=v"(r) : "v"(x));  // (low half >> 8, upper half cleared: one cheap instruction)
+            return r;
+        }
+        case 2: return (x >> 16) & 0xFFu;
+        default: return x >> 24;
+    }
+}
+__device__ __forceinline__ uint32_t field_at(const uint32_t *w, uint32_t j, int16_t) {
+    const uint32_t x = w[j >> 1] ^ 0x80008000u;
+    return (j & 1u) ? x >> 16 : x & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t field_of(int v, uint8_t) { return (uint32_t)v & 0xFFu; }
+__device__ __forceinline__ uint32_t field_of(int v, int16_t) { return ((uint32_t)v ^ 0x8000u) & 0xFFFFu; }
+
 // ------------------------------------------------------------------------------------------
 // k_front: the ONE classification of a pixel, and the sort of a tile's events by context.  One workgroup per tile of
 // SORT_TILE pixels, a quarter of the tile per wave.
@@ -121,9 +175,8 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 5))) __global__ __launch
     constexpr uint32_t KEY = 0xFFC01FFFu;  // context and pixel offset of a record
     static_assert(SORT_TILE % 1024 == 0 && SORT_TILE <= (1u << 13), "four whole trips per wave; 13 bits of pixel offset");
     static_assert(NC % 256 == 0 && NC <= 512, "a thread takes NC / 256 contexts; 9 bits of context");
-    __shared__ uint32_t srt[SORT_TILE + 1];   // the tile's events, contexts ascending, raster order inside (+ a sentinel behind the last)
-    __shared__ uint32_t stages[4][256];       // per wave: the events of one trip in raster order, on their way into registers
-    __shared__ uint32_t cnt[4][NC];           // per wave and context: count, then cursor into srt
+    __shared__ uint32_t srt[SORT_TILE + 1 + 256];  // the tile's events, contexts ascending, raster order inside, a sentinel behind the last; [.. + 1 + thread]: where slots without an event are "placed"
+    __shared__ uint32_t cnt[4][NC + 64];      // per wave and context: count, then cursor into srt; [NC + lane]: what slots without an event count on
     __shared__ uint32_t gdst[NC];             // a context's run: its place among the tile's slots minus its place in srt
     __shared__ uint32_t wsum[4];
     // (wave-uniform, and said so: the tile, its bounds and the trip bookkeeping then live in scalar registers instead of vector
@@ -146,22 +199,35 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 5))) __global__ __launch
     const uint32_t begin = tile * SORT_TILE;
     const uint32_t qbegin = min(begin + wave * QUARTER, npix);
     const uint32_t end = min(qbegin + QUARTER, npix);  // of this wave's quarter
-    uint32_t *stage = stages[wave];
     const bool safe_rank = (mode & FRONT_SAFE_RANK) != 0;
-    // ---- 1, 2. classify, compact, rank.  The events of a trip are compacted, raster order kept, into the wave's staging buffer and
-    // read back 64 at a time into registers: event 64 u + lane of trip d lives in slot (d, u) of this lane -- static slots, plain
-    // assignments (a value merged across a branch costs a register copy) -- together with its rank within (wave, context)
-    constexpr uint32_t BPT = 4, SLOTS = TRIPS * BPT;  // up to 256 events per trip
-    uint32_t rec[SLOTS], rk[SLOTS], nd[TRIPS];
+    // ---- 1, 2. classify and rank, no compaction: a trip is 256 consecutive pixels, lane l takes pixels l, l + 64, l + 128, l + 192
+    // of it -- so that the raster order of a trip's pixels is (sub-row, lane) and ONE returning LDS add per sub-row ranks its events
+    // within (wave, context) in raster order (ascending lanes).  Every pixel keeps a static slot of this lane: its record
+    // (context << 22 | value << 13 | offset in the tile; all ones where the pixel is no event) and its rank.  A slot without an event
+    // adds to a counter of its own lane (no exec mask around the atomic).  (Round 4 compacted a trip's events through LDS first so
+    // that every atomic ranked 64 events: a scan, four masked LDS writes and four reads per trip for half as many atomics.)
+    constexpr uint32_t SLOTS = TRIPS * 4;
+    uint32_t rec[SLOTS], rk[SLOTS];
     auto is_interior = [&](uint32_t r, uint32_t x, uint32_t y) { return y > 0 && x + 256 <= W && r + 256 <= end; };  // (a span from the first column included)
-    Interior4<T> pre[TRIPS];
+    struct Trip {  // the samples of an interior trip as loaded: four of the row, four of the row above, the one in front of the span
+        uint32_t cur[4], up[4], left0;
+    };
+    auto load_trip = [&](uint32_t r, uint32_t left_index, Trip &t) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            t.cur[j] = field_of((int)pl[r + 64 * j + lane], T());
+            t.up[j] = field_of((int)pl[r + 64 * j + lane - W], T());
+        }
+        t.left0 = field_of((int)pl[left_index], T());  // (the same address in every lane)
+    };
     bool have[TRIPS];
+    uint32_t leftidx[TRIPS];
     {
         uint32_t ri = qbegin, yi = qbegin / W, xi = qbegin - yi * W;
 #pragma unroll
         for (uint32_t d = 0; d < TRIPS; d++) {
             have[d] = ri < end && is_interior(ri, xi, yi);
-            if (have[d]) load_interior4(pl, ri, W, span_left_index(ri, xi, yi, W), pre[d]);
+            leftidx[d] = have[d] ? span_left_index(ri, xi, yi, W) : 0u;
             ri += 256;
             xi += 256;
             if (xi >= W) {  // (once per image row: scalar division)
@@ -171,82 +237,74 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 5))) __global__ __launch
             }
         }
     }
+    const uint32_t cnt_at = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t *)my_cnt;  // LDS address of the wave's counters
+    const uint32_t dummy_at = (NC + lane) * 4u;
+    Trip pre[2];  // two trips in flight
+    if (have[0]) load_trip(qbegin, leftidx[0], pre[0]);
 #pragma unroll
     for (uint32_t d = 0; d < TRIPS; d++) {
         const uint32_t row0 = qbegin + d * 256;
-        uint32_t n = 0;  // events of this trip (wave-uniform)
+        if (d + 1 < TRIPS && have[d + 1]) load_trip(row0 + 256, leftidx[d + 1], pre[(d + 1) & 1u]);
         if (have[d]) {
-            const uint32_t off0 = row0 - begin + 4 * lane;
-            PixelClass pc[4];
-            classify_loaded4(pre[d], pc);
-            uint32_t nev = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) nev += pc[j].cls != CLS_IN ? 1u : 0u;
-            const uint32_t incl = wave_incl_scan(nev);
-            uint32_t pos = incl - nev;
+            const Trip &t = pre[d & 1u];
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
-                if (pc[j].cls != CLS_IN) {
-                    stage[pos] = (pc[j].ctx << 22) | (pc[j].val << 13) | (off0 + j);
-                    pos++;
-                }
+                // the left neighbour: the lane before; lane 0 takes the last lane of the sub-row before (the sample in front of the
+                // span for the first sub-row: the first-column rule's second neighbour if the span starts in column 0, misc.rs:14-23)
+                uint32_t edge = t.left0;
+                if (j > 0) edge = readlane(t.cur[j - 1], 63);
+                const uint32_t a = (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)t.cur[j], 0x138, 0xF, 0xF, false);  // wave_shr:1
+                const uint32_t p = t.cur[j], b = t.up[j];
+                // compression.rs:124-145 on unsigned 16-bit fields, selects as sign masks (the 1.0 ns instruction class, as in code_pixel)
+                const uint32_t L = min_u16(a, b), H = max_u16(a, b);
+                const uint32_t ctx = H - L;
+                const int dd = (int)(p - L);         // in range: 0 <= dd <= ctx
+                const int below = dd >> 31;          // all ones: p < L
+                const int o = (int)(p - H) - 1;      // >= 0: p > H
+                const int not_above = o >> 31;
+                const uint32_t val = bitop3<BT_SEL>((uint32_t)(dd ^ below), (uint32_t)o, (uint32_t)not_above);  // L - p - 1 | p - L | p - H - 1
+                const uint32_t in_range = bitop3<BT_ANDN>((uint32_t)not_above, (uint32_t)below, 0u);               // all ones: no event
+                const uint32_t off = row0 - begin + 64 * j + lane;
+                rec[d * 4 + j] = ((ctx << 22) | (val << 13) | off) | in_range;
+                // rank: the counter of the event's context, or this lane's own
+                const uint32_t at = cnt_at + bitop3<BT_SEL>(dummy_at, ctx << 2, in_range);
+                if (!safe_rank)
+                    rk[d * 4 + j] = __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)(uintptr_t)at, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            n = readlane(incl, 63);
         } else {  // (a trip that crosses a row end, lies in the first row or ends the plane: the general neighbour rule)
-            bool evs[4];
-            uint32_t cs[4], es[4];
             Coord xy;
             xy.set(row0 + lane, W);
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t i = row0 + u * 64 + lane;
-                evs[u] = false;
-                cs[u] = 0;
-                es[u] = 0;
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t i = row0 + j * 64 + lane;
+                uint32_t r = 0xFFFFFFFFu;
                 if (i < end && i >= 2) {
                     const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
-                    evs[u] = pc.cls != CLS_IN;
-                    cs[u] = pc.ctx;
-                    es[u] = pc.val;
+                    if (pc.cls != CLS_IN) r = (pc.ctx << 22) | (pc.val << 13) | (i - begin);
                 }
                 xy.advance(64, W);
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {  // row by row, lane by lane
-                const uint64_t m = __ballot(evs[u]);
-                if (m == 0) continue;
-                if (evs[u]) stage[n + mbcnt(m)] = (cs[u] << 22) | (es[u] << 13) | (row0 - begin + u * 64 + lane);
-                n += (uint32_t)__popcll(m);
+                rec[d * 4 + j] = r;
+                const uint32_t at = cnt_at + ((int)r < 0 ? dummy_at : (r >> 22) << 2);
+                if (!safe_rank)
+                    rk[d * 4 + j] = __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)(uintptr_t)at, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        nd[d] = n;
-        __builtin_amdgcn_wave_barrier();
+        if (safe_rank) {
+            // ranks from ballots: every lane learns the lanes that hold its context, one ballot per context bit; its rank = the
+            // context's count so far + the lanes in front of it, the first lane of a context adds the sub-row's share to the count
 #pragma unroll
-        for (uint32_t u = 0; u < BPT; u++) rec[d * BPT + u] = stage[u * 64 + lane];  // (past n: whatever the buffer held, not used)
-        if (!safe_rank) {
-#pragma unroll
-            for (uint32_t u = 0; u < BPT; u++) {
-                uint32_t r = 0;
-                if (u * 64 + lane < n) r = atomicAdd(&my_cnt[rec[d * BPT + u] >> 22], 1u);
-                rk[d * BPT + u] = r;
-            }
-        } else {
-            // ranks from ballots: every lane learns the lanes that hold its context, one ballot per
-            // context bit; its rank = the context's count so far + the lanes in front of it, the first lane of a context adds
-            // the batch's share to the count
-#pragma unroll
-            for (uint32_t u = 0; u < BPT; u++) {
-                const bool e = u * 64 + lane < n;
-                const uint32_t c = (rec[d * BPT + u] >> 22) & (NC - 1u);
+            for (uint32_t j = 0; j < 4; j++) {
+                const bool e = (int)rec[d * 4 + j] >= 0;
+                const uint32_t c = (rec[d * 4 + j] >> 22) & (NC - 1u);
                 const uint64_t ev_mask = __ballot(e);
                 uint32_t m_lo = (uint32_t)ev_mask, m_hi = (uint32_t)(ev_mask >> 32);
                 constexpr uint32_t CTX_BITS = NC == 256 ? 8 : 9;
 #pragma unroll
-                for (uint32_t b = 0; b < CTX_BITS; b++) {
-                    const uint32_t t = (uint32_t)((int32_t)(c << (31 - b)) >> 31);  // all ones if bit b of c is set
-                    const uint64_t bb = __ballot(e && t != 0);
-                    m_lo &= ~((uint32_t)bb ^ t);
-                    m_hi &= ~((uint32_t)(bb >> 32) ^ t);
+                for (uint32_t bt = 0; bt < CTX_BITS; bt++) {
+                    const uint32_t tt = (uint32_t)((int32_t)(c << (31 - bt)) >> 31);  // all ones if bit bt of c is set
+                    const uint64_t bb = __ballot(e && tt != 0);
+                    m_lo &= ~((uint32_t)bb ^ tt);
+                    m_hi &= ~((uint32_t)(bb >> 32) ^ tt);
                 }
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
                 const uint32_t group = (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);
@@ -255,10 +313,9 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 5))) __global__ __launch
                 __builtin_amdgcn_wave_barrier();
                 if (e && rank == 0) my_cnt[c] = r + group;
                 __builtin_amdgcn_wave_barrier();
-                rk[d * BPT + u] = r;
+                rk[d * 4 + j] = r;
             }
         }
-        __builtin_amdgcn_wave_barrier();  // (the next trip writes the staging buffer again)
     }
     __syncthreads();
     // ---- 3. the tile's layout: thread t takes contexts t * PER ..; two running sums in one register: the events in front (low
@@ -322,15 +379,18 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 5))) __global__ __launch
         }
     }
     __syncthreads();
-    // ---- 4. place: where the context's events of this wave start + the event's rank among them
+    // ---- 4. place: where the context's events of this wave start + the event's rank among them (a slot without an event: a
+    // place of this thread's own behind the tile)
 #pragma unroll
     for (uint32_t q0 = 0; q0 < SLOTS; q0 += 8) {
         uint32_t at[8];
 #pragma unroll
-        for (uint32_t q = 0; q < 8; q++) at[q] = my_cnt[(rec[q0 + q] >> 22) & (NC - 1u)];  // (masked: an unused slot holds anything)
+        for (uint32_t q = 0; q < 8; q++) at[q] = my_cnt[(rec[q0 + q] >> 22) & (NC - 1u)];  // (masked: a slot without an event holds all ones)
 #pragma unroll
-        for (uint32_t q = 0; q < 8; q++)
-            if (((q0 + q) % BPT) * 64 + lane < nd[(q0 + q) / BPT]) srt[at[q] + rk[q0 + q]] = rec[q0 + q];
+        for (uint32_t q = 0; q < 8; q++) {
+            const uint32_t none = (uint32_t)((int)rec[q0 + q] >> 31);
+            srt[bitop3<BT_SEL>(SORT_TILE + 1u + tid, at[q] + rk[q0 + q], none)] = rec[q0 + q];
+        }
     }
     __syncthreads();
     // ---- 5. out, checked: (context, pixel offset) must ascend strictly -- exactly "stable partition by context"
@@ -862,60 +922,6 @@ __device__ __forceinline__ GroupGeom group_geometry(const T *__restrict__ pl, ui
     }
     return gg;
 }
-
-// ---- Instruction forms.  profiles/r04/valu_rate.txt: a gfx950 SIMD issues 32-bit add / sub / and / or / xor / lshr / ashr,
-// v_bitop3_b32 and every 16-bit VOP2 instruction (min, max, add, shifts) in 1.0 ns, everything else -- v_min_u32,
-// v_lshlrev_b32, v_cndmask, compares, v_bfe, SDWA / DPP / VOP3 forms, 64-bit shifts -- in 1.7 ns.  The compiler prices them
-// alike and turns sign masks back into compare + select, so the code builder names the cheap forms itself.
-template <uint32_t TABLE>
-__device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
-    return __builtin_amdgcn_bitop3_b32(a, b, c, TABLE);  // bit i of the result = TABLE[a_i << 2 | b_i << 1 | c_i]
-}
-constexpr uint32_t BT_SEL = 0xE4;      // c ? a : b  =  (a & c) | (b & ~c)
-constexpr uint32_t BT_OR_ANDN = 0xF4;  // a | (b & ~c)
-constexpr uint32_t BT_ANDN = 0x30;     // a & ~b
-__device__ __forceinline__ uint32_t min_u16(uint32_t a, uint32_t b) {  // operands < 2^16
-    uint32_t r;
-    asm("v_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ uint32_t max_u16(uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("v_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ uint32_t twice(uint32_t a) {  // a + a as an add (the compiler would make it a left shift)
-    uint32_t r;
-    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(a));
-    return r;
-}
-__device__ __forceinline__ uint32_t vgpr_const(uint32_t v) {  // a constant kept in a vector register: the shifted operand of v_lshrrev_b32_e32
-    uint32_t r;
-    asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
-    return r;
-}
-
-// Sample j of a group held in packed registers, as an unsigned 16-bit value in an order-preserving offset: u8 samples as
-// they are, i16 samples (Y / Co / Cg planes) with the sign bit flipped -- the codes depend on differences only.
-__device__ __forceinline__ uint32_t field_at(const uint32_t *w, uint32_t j, uint8_t) {
-    const uint32_t x = w[j >> 2];
-    switch (j & 3u) {
-        case 0: return x & 0xFFu;
-        case 1: {
-            uint32_t r;
-            asm("v_lshrrev_b16 %0, 8, %1" : "=v"(r) : "v"(x));  // (low half >> 8, upper half cleared: one cheap instruction)
-            return r;
-        }
-        case 2: return (x >> 16) & 0xFFu;
-        default: return x >> 24;
-    }
-}
-__device__ __forceinline__ uint32_t field_at(const uint32_t *w, uint32_t j, int16_t) {
-    const uint32_t x = w[j >> 1] ^ 0x80008000u;
-    return (j & 1u) ? x >> 16 : x & 0xFFFFu;
-}
-__device__ __forceinline__ uint32_t field_of(int v, uint8_t) { return (uint32_t)v & 0xFFu; }
-__device__ __forceinline__ uint32_t field_of(int v, int16_t) { return ((uint32_t)v ^ 0x8000u) & 0xFFFFu; }
 
 // One pixel's code, left-aligned in 32 bits, and its length (compression.rs:124-145): p against its two neighbours a, b
 // (unordered; all three in field_at's form), k = the Rice parameter of the pixel's context (used if p is out of range).

@@ -302,7 +302,8 @@ def test_pack_variants(oracle):
             assert e.compress_batch(rgb) == [oracle.compress(f) for f in rgb], env
             st = e.stats()
             if "FELICS_TEST_LOOKBACK_FAIL" in env:  # tickets first (unless the context started with them), then two passes
-                assert st["two_pass"] == 1 and st["lookback_fallbacks"] == (1 if "FELICS_OWN_TAILS" in env else 2), (env, st)
+                # (the host entry point queues its chunks two deep: the chunk in flight beside the first failure reports one as well)
+                assert st["two_pass"] == 1 and st["lookback_fallbacks"] == (2 if "FELICS_OWN_TAILS" in env else 3), (env, st)
                 assert st["ticket_retries"] == (0 if "FELICS_OWN_TAILS" in env else 1), (env, st)
             else:
                 assert st["two_pass"] == (1 if "FELICS_TWO_PASS" in env else 0) and st["lookback_fallbacks"] == 0, (env, st)
@@ -310,6 +311,40 @@ def test_pack_variants(oracle):
             assert st["tile_overflows"] == (1 if "FELICS_TEST_TILE_CAP" in env else 0), (env, st)
         finally:
             e.close()
+
+
+def test_lookback_failure_with_two_submissions_in_flight(oracle):
+    """Two queued submissions, both launched without tickets, whose look-backs both give up (FELICS_TEST_LOOKBACK_FAIL): the first
+    wait turns tickets on and -- its redo failing with tickets as well -- moves the context to the two-pass kernels; the second
+    wait finds a sub-batch that ran WITHOUT tickets, so it counts a fallback but does not escalate on its own account
+    (felics_api.cpp: note_lookback_failure looks at what the failed sub-batch was launched with).  Streams equal the oracle's."""
+    import torch
+    import felics_amd
+    from felics_amd import synth
+
+    frames = [synth.gray8(800, 600, f, "S1") for f in range(4)]
+    want = [oracle.compress(f) for f in frames]
+    os.environ["FELICS_TEST_LOOKBACK_FAIL"] = "1"
+    try:
+        e = felics_amd.Encoder(0)
+    finally:
+        del os.environ["FELICS_TEST_LOOKBACK_FAIL"]
+    try:
+        cap = 800 * 600 * 4 * 2
+        d_in = torch.from_numpy(np.stack(frames)).cuda()
+        outs = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        torch.cuda.synchronize()
+        tickets = [e.submit_batch_device(d_in.data_ptr(), 4, 800, 600, 0, 0, outs[i].data_ptr(), cap) for i in range(2)]
+        for i, t in enumerate(tickets):
+            offs, lens = e.wait_batch(t)
+            host = outs[i].cpu().numpy()
+            for j in range(4):
+                assert host[int(offs[j]): int(offs[j] + lens[j])].tobytes() == want[j], (i, j)
+        st = e.stats()
+        assert st["two_pass"] == 1 and st["ticket_retries"] == 1 and st["lookback_fallbacks"] == 3, st
+        assert e.compress_batch(frames) == want  # the context, now on the two-pass kernels
+    finally:
+        e.close()
 
 
 def test_queued_submissions_of_changing_content(oracle):

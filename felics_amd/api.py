@@ -228,7 +228,10 @@ class Encoder:
             lens = (C.c_size_t * n)()
             rc = lib().felics_compress_batch(self._h, n, px, w, h, int(color), int(depth), op, cp, lens)
             if rc == -8:  # grow to the sizes the library reported and submit again
-                caps = [max(c, int(l)) for c, l in zip(caps, lens)]
+                grown = [max(c, int(l)) for c, l in zip(caps, lens)]
+                if grown == caps:  # (nothing to grow by: not a size of ours -- do not spin)
+                    self._raise(rc)
+                caps = grown
                 continue
             if rc != 0:
                 self._raise(rc)

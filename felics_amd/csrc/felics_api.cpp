@@ -134,10 +134,11 @@ struct felics_ctx {
     float stage_ms[ST_COUNT] = {};
     float span_ms = 0.f;        // profiling: first kernel -> sizes on the host, of the last submission collected
     int stage_launches[ST_COUNT] = {};
-    DevBuf in, out;  // staging of the host-pointer entry points
+    DevBuf in, out;  // staging of the host-pointer entry point: the batch's frames, the chunks' output slots
     hipStream_t copy_in = nullptr, copy_out = nullptr;  // felics_compress_batch: frames to the device / streams back, beside the kernels
     hipEvent_t h2d_done[MAX_LANES] = {};                // a chunk's frames have arrived (one per lane)
     hipEvent_t wait_before_submit = nullptr;            // the next sub-batch's first kernel waits for this event (set around one submit)
+    DevBuf own;      // encode_device's own output when the caller gives none (the host entry point's fall-back for a chunk whose streams outgrew their slots)
     DevBuf dec_meta, dec_planes;  // GPU decoder: offsets | lens | status of a batch; Y / Co / Cg planes of RGB streams
     DevBuf dec_lane_table;        // gray streams decoded 64 to a wave: the estimator rows that do not fit in LDS (3 KB per stream, zeroed per call)
     DevBuf dec_table;             // 16-bit streams: estimator tables in HBM (8.4 MB per stream of a pass), zeroed once, rows tagged with an epoch
@@ -741,10 +742,10 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
         const size_t stride = (sz + 15) & ~(size_t)15;
         const size_t need = stride * n;
         if (own_out) {
-            int rc = reserve(ctx, ctx->out, need);
+            int rc = reserve(ctx, ctx->own, need);
             if (rc) return rc;
-            d_out = (uint8_t *)ctx->out.p;
-            d_out_cap = ctx->out.cap;
+            d_out = (uint8_t *)ctx->own.p;
+            d_out_cap = ctx->own.cap;
         }
         if (need > d_out_cap) {
             if (n) lens[0] = need;
@@ -771,9 +772,9 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
     uint64_t slot = 0;
     if (own_out) {
         slot = ((uint64_t)frame_bytes + frame_bytes / 4 + 64 + 15) & ~15ull;
-        if ((rc = reserve(ctx, ctx->out, (size_t)(slot * n))) != 0) return rc;
-        d_out = (uint8_t *)ctx->out.p;
-        d_out_cap = ctx->out.cap;
+        if ((rc = reserve(ctx, ctx->own, (size_t)(slot * n))) != 0) return rc;
+        d_out = (uint8_t *)ctx->own.p;
+        d_out_cap = ctx->own.cap;
     } else {
         slot = (d_out_cap / n) & ~15ull;
         if (slot < 64 || slot < frame_bytes / 4) slot = 0;
@@ -810,9 +811,9 @@ int encode_device(felics_ctx *ctx, Lane &l, size_t n, const void *d_pixels, uint
                 }
                 if (own_out) {
                     if (done != 0) return FELICS_E_UNSUPPORTED;  // the host entry points submit one pass at a time
-                    if ((rc = reserve(ctx, ctx->out, (size_t)need)) != 0) return rc;  // waits for the device
-                    d_out = (uint8_t *)ctx->out.p;
-                    d_out_cap = ctx->out.cap;
+                    if ((rc = reserve(ctx, ctx->own, (size_t)need)) != 0) return rc;  // waits for the device
+                    d_out = (uint8_t *)ctx->own.p;
+                    d_out_cap = ctx->own.cap;
                 }
                 if (need > d_out_cap) {
                     (void)sync_lane(ctx, l);
@@ -985,12 +986,13 @@ void felics_ctx_destroy(felics_ctx *ctx) {
         if (l.stream) (void)hipStreamDestroy(l.stream);
         if (l.tail && (&l == &ctx->lanes[0] || l.tail != ctx->lanes[0].tail)) (void)hipStreamDestroy(l.tail);
     }
+    release(ctx->in);
     if (ctx->copy_in) (void)hipStreamSynchronize(ctx->copy_in), (void)hipStreamDestroy(ctx->copy_in);
     if (ctx->copy_out) (void)hipStreamSynchronize(ctx->copy_out), (void)hipStreamDestroy(ctx->copy_out);
     for (hipEvent_t ev : ctx->h2d_done)
         if (ev) (void)hipEventDestroy(ev);
-    release(ctx->in);
     release(ctx->out);
+    release(ctx->own);
     release(ctx->dec_meta);
     release(ctx->dec_planes);
     release(ctx->dec_table);
@@ -1107,9 +1109,11 @@ int felics_wait_batch(felics_ctx *ctx, int ticket, uint64_t *offsets, uint64_t *
 // The reference's own call shape: images in host memory in, .felics bytes in host memory out (compression.rs:255-282, :322-371;
 // cfelics.rs:24-31).  The batch goes through the submission queue in CHUNKS: the frames of chunk c + 1 are copied to the device
 // on a copy stream of its own while chunk c is encoded and the streams of chunk c - 1 are copied back on a third stream, so the
-// link is busy in both directions under the kernels.  (The copies are hipMemcpyAsync from / to the caller's pointers: at the
+// link is busy in both directions under the kernels (measured, 64 4K gray8 frames from and to page-locked memory: 13.8 ms per
+// batch; with the copies on the lanes' own streams 15.6).  (The copies are hipMemcpyAsync from / to the caller's pointers: at the
 // link's rate, and asynchronous, if that memory is page-locked -- hipHostMalloc, hipHostRegister, a pinned torch tensor -- and
-// through the runtime's staging otherwise.)
+// through the runtime's staging otherwise.)  A chunk whose streams outgrow their slots and the room the slots leave for exact
+// placement is encoded once more, blocking, into a buffer that grows.
 int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, uint32_t w, uint32_t h, int color,
                           int depth, uint8_t *const *outs, const size_t *caps, size_t *lens) {
     if (!ctx || (n && (!pixels || !outs || !caps || !lens))) return FELICS_E_INVALID_ARGUMENT;
@@ -1144,6 +1148,18 @@ int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, 
     int result = FELICS_OK;
     auto land = [&](const Flying &f) -> int {  // wait for a chunk and start its streams on their way to the caller
         int r = felics_wait_batch(ctx, f.ticket, offs.data(), sizes.data());
+        const uint8_t *from = (const uint8_t *)ctx->out.p + f.first * slot;
+        hipStream_t cs = ctx->copy_out;
+        if (r == FELICS_E_BUFFER_TOO_SMALL) {
+            // The chunk's streams outgrew their slots AND the room the slots leave for exact placement (16-bit noise: a code can be
+            // 2^17 bits): once more, blocking, into a buffer of the library's own that grows to what the streams need.
+            Lane &l = ctx->lanes[f.ticket];
+            uint8_t *d_own = nullptr;
+            r = encode_device(ctx, l, f.cnt, (const uint8_t *)ctx->in.p + f.first * frame_bytes, w, h, color, depth, nullptr, 0, offs.data(),
+                              sizes.data(), &d_own);
+            from = d_own;
+            cs = l.stream;  // (copied out before anything else may touch ctx->own: synchronised below)
+        }
         if (r) return r;
         for (size_t i = 0; i < f.cnt; i++) {
             lens[f.first + i] = (size_t)sizes[i];
@@ -1151,9 +1167,9 @@ int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, 
                 result = FELICS_E_BUFFER_TOO_SMALL;  // lens[] still reports every size needed
                 continue;
             }
-            HIP_TRY(ctx, hipMemcpyAsync(outs[f.first + i], (uint8_t *)ctx->out.p + f.first * slot + offs[i], (size_t)sizes[i],
-                                        hipMemcpyDeviceToHost, ctx->copy_out));
+            HIP_TRY(ctx, hipMemcpyAsync(outs[f.first + i], from + offs[i], (size_t)sizes[i], hipMemcpyDeviceToHost, cs));
         }
+        if (from != (const uint8_t *)ctx->out.p + f.first * slot) HIP_TRY(ctx, hipStreamSynchronize(cs));
         return FELICS_OK;
     };
     auto drain = [&](int r) {  // an error: nothing of this context may be left in flight behind the caller's back
@@ -1164,12 +1180,12 @@ int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, 
     };
     for (size_t first = 0; first < n; first += chunk) {
         const size_t cnt = std::min(chunk, n - first);
-        for (size_t i = 0; i < cnt && frame_bytes; i++) {
+        for (size_t i = 0; i < cnt && frame_bytes; i++) {  // the chunk's frames, on their way while the chunks before it are encoded
             const hipError_t e = hipMemcpyAsync((uint8_t *)ctx->in.p + (first + i) * frame_bytes, pixels[first + i], frame_bytes,
                                                 hipMemcpyHostToDevice, ctx->copy_in);
             if (e != hipSuccess) return drain(hip_fail(ctx, e, "copying frames to the device"));
         }
-        if ((int)flying.size() == ctx->nlanes) {  // every lane is busy: the oldest chunk first
+        if ((int)flying.size() == ctx->nlanes) {  // every lane is busy: the oldest chunk first (its lane is the next to be used)
             rc = land(flying.front());
             flying.erase(flying.begin());
             if (rc) return drain(rc);
@@ -1189,7 +1205,7 @@ int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, 
         flying.erase(flying.begin());
         if (rc) return drain(rc);
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_out));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_out));  // the streams have landed
     return result;
 }
 

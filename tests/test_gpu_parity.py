@@ -307,8 +307,9 @@ def test_pack_variants(oracle):
                 assert st["ticket_retries"] == (0 if "FELICS_OWN_TAILS" in env else 1), (env, st)
             else:
                 assert st["two_pass"] == (1 if "FELICS_TWO_PASS" in env else 0) and st["lookback_fallbacks"] == 0, (env, st)
-            assert st["scatter_fallbacks"] == (1 if "FELICS_TEST_SCATTER_ORDER" in env else 0), (env, st)
-            assert st["tile_overflows"] == (1 if "FELICS_TEST_TILE_CAP" in env else 0), (env, st)
+            # (the host entry point queues its chunks two deep: the chunk in flight beside the first failure reports one as well)
+            assert st["scatter_fallbacks"] in ((1, 2) if "FELICS_TEST_SCATTER_ORDER" in env else (0,)), (env, st)
+            assert st["tile_overflows"] in ((1, 2) if "FELICS_TEST_TILE_CAP" in env else (0,)), (env, st)
         finally:
             e.close()
 

@@ -355,10 +355,10 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
 
     uint32_t bounds[SLICES + 1];  // slice boundaries in sort tiles (= pack tiles)
     for (int q = 0; q <= ns; q++) bounds[q] = (uint32_t)((uint64_t)g.sort_tiles * q / ns);
-    // the records of slice q live in their own region of desc / state16: as many as its tiles can hold
+    // the records of slice q live in their own region of desc: as many as its tiles can hold
     auto slice_of = [&](int q) {
         const size_t r0 = (size_t)bounds[q] * g.nplanes * (cap / REC);
-        return ChainSlice{(uint2 *)l.desc.p + r0, (uint2 *)l.partial.p + (size_t)q * nchains, d_nrec + q, (uint4 *)l.block_state.p + r0};
+        return ChainSlice{(uint2 *)l.desc.p + r0, (uint2 *)l.partial.p + (size_t)q * nchains, d_nrec + q, (uint4 *)l.block_state.p};
     };
     // ---- front stream
     if (ctx->poison) {  // FELICS_POISON: every intermediate buffer starts as garbage, as on a fresh context
@@ -400,7 +400,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
         HIP_TRY(ctx, hipStreamWaitEvent(ks, l.spine_done[q], 0));
         if (bounds[q + 1] != bounds[q]) {
             StageTimer t(ctx, l, ST_ASSIGN, ks, true);
-            launch_assign3<ET>(ks, tloc.ev, slice_of(q), tloc.kq, g);
+            launch_assign3<ET>(ks, tloc, (const uint4 *)l.block_state.p, g, bounds[q], bounds[q + 1]);
         }
         HIP_TRY(ctx, hipEventRecord(l.assign_done[q], ks));
     }
@@ -895,7 +895,8 @@ int felics_ctx_create(int device, felics_ctx **out) {
     if (const char *e = getenv("FELICS_SCATTER")) ctx->scatter_ballot = !strcmp(e, "ballot");
     ctx->test_tile_cap = getenv("FELICS_TEST_TILE_CAP") != nullptr;
     ctx->test_scatter_order = getenv("FELICS_TEST_SCATTER_ORDER") != nullptr;
-    ctx->pack_tickets = ctx->own_tails = getenv("FELICS_OWN_TAILS") != nullptr;
+    ctx->own_tails = getenv("FELICS_OWN_TAILS") != nullptr;
+    ctx->pack_tickets = ctx->own_tails && atoi(getenv("FELICS_OWN_TAILS")) != 2;
     ctx->serial = getenv("FELICS_SERIAL") != nullptr;
     ctx->test_timeout = getenv("FELICS_TEST_TIMEOUT") != nullptr;
     if (const char *e = getenv("FELICS_SLICES")) ctx->slices_blocking = std::max(1, std::min(atoi(e), SLICES));

@@ -376,9 +376,10 @@ __device__ __forceinline__ bool spine3_walk(Spine3LDS &sh, uint32_t w, uint32_t 
     return ok;
 }
 
-// helper, window w (after it was walked): the start state of lane's record, stored with the record's place
+// helper, window w (after it was walked): the start state of lane's record, stored AT the record's place (its slot group over
+// the whole sub-batch: k_assign3 takes the records in tile order)
 __device__ __forceinline__ void spine3_finish(Spine3LDS &sh, uint32_t w, uint32_t nvalid /* records of the window */,
-                                              uint4 *__restrict__ out /* of the window's first record */) {
+                                              uint4 *__restrict__ state16 /* [record's place] */) {
     const uint32_t lane = lane_id();
     const uint32_t *cT = sh.cumT[w % 3u] + lane * SP3_CROW;  // row lane = through record lane - 1
     const uint64_t hm = ((uint64_t)sh.hmask[w & 1u][1] << 32) | sh.hmask[w & 1u][0];
@@ -387,8 +388,8 @@ __device__ __forceinline__ void spine3_finish(Spine3LDS &sh, uint32_t w, uint32_
     const uint32_t *lD = sh.lastD[w & 1u] + row * 8;
     const uint32_t s0 = lD[0] + cT[0], s1 = lD[1] + cT[1], s2 = lD[2] + cT[2];
     const uint32_t s3 = lD[3] + cT[3], s4 = lD[4] + cT[4], s5 = lD[5] + cT[5];
-    if (lane < nvalid)
-        out[lane] = make_uint4((s0 & 0xFFFFu) | (s1 << 16), (s2 & 0xFFFFu) | (s3 << 16), (s4 & 0xFFFFu) | (s5 << 16), sh.grec[w % 3u][lane]);
+    const uint32_t place = sh.grec[w % 3u][lane];
+    if (lane < nvalid) state16[place] = make_uint4((s0 & 0xFFFFu) | (s1 << 16), (s2 & 0xFFFFu) | (s3 << 16), (s4 & 0xFFFFu) | (s5 << 16), place);
 }
 
 template <typename ET>
@@ -410,7 +411,6 @@ __global__ __launch_bounds__(128) void k_spine3(const ET *__restrict__ ev, const
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t nwin = (nrec + 63u) >> 6;
     const uint2 *dsc = desc + rec0;
-    uint4 *out = state16 + rec0;
     uint32_t *cstate = chain_state + (uint64_t)chain * 8;
     // cumT: row 0 of every buffer is zeros (the window's sums in front of its first record), and so are the words behind the
     // six counters in every row (the walker reads a row as a state vector of eight); nobody writes them again
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(128) void k_spine3(const ET *__restrict__ ev, const
             ok = spine3_walk(sh, 0, Sv) && ok;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            spine3_finish(sh, 0, min(64u, nrec - w * 64), out + (uint64_t)w * 64);
+            spine3_finish(sh, 0, min(64u, nrec - w * 64), state16);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         if (lane < 6) cstate[lane] = Sv;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(128) void k_spine3(const ET *__restrict__ ev, const
         for (uint32_t it = 0; it < nwin + 2; it++) {
             const uint2 d5 = fetch_desc(it + 5);  // (windows past the last: no records, nothing read)
             load_record(ev, d3.x, e3);
-            if (it >= 2) spine3_finish(sh, it - 2, min(64u, nrec - (it - 2) * 64), out + (uint64_t)(it - 2) * 64);
+            if (it >= 2) spine3_finish(sh, it - 2, min(64u, nrec - (it - 2) * 64), state16);
             if (it < nwin) spine3_produce<ET>(sh, it, e0, d0.y, d0.x);
             e0 = e1;
             e1 = e2;
@@ -533,25 +533,47 @@ template void launch_spine3<uint8_t>(hipStream_t, const uint8_t *, const ChainSl
 template void launch_spine3<uint16_t>(hipStream_t, const uint16_t *, const ChainSlice &, uint32_t *, uint32_t *, const Geometry &);
 
 // ------------------------------------------------------------------------------------------
-// k_assign3: k of every event, one LANE per record.
+// k_assign3: k of every event, one LANE per record, records in TILE order.
 //
-// A lane loads its record's start state (k_spine3) and its 16 events and replays the estimator event by event
-// (parameter_selection.rs:49-85): k = argmin of the six counters, ties to the largest k (`<=` at :79), taken BEFORE the
-// update (compression.rs:127,139); update; halve when the minimum exceeds 1024.  No cross-lane operation.  The record's 16
-// k bytes leave as one 16-byte store into the tile's k bytes (kq[slot]), which the pack stage reads back contiguously.
-// Slots behind a run's last event are replayed like events: their k is never read (pix = 0xFFFF there) and the state they
-// leave goes nowhere (the next record has its own start state).
-// Persistent: a fixed grid strides over the slice's records (their number is only known on the device).
+// A lane loads its record's start state (k_spine3 left it at the record's place: state16[slot / REC]) and its 16 events and
+// replays the estimator event by event (parameter_selection.rs:49-85): k = argmin of the six counters, ties to the largest k
+// (`<=` at :79), taken BEFORE the update (compression.rs:127,139); update; halve when the minimum exceeds 1024.  No
+// cross-lane operation.  The record's 16 k bytes leave as one 16-byte store into the tile's k bytes (kq[slot]), which the
+// pack stage reads back contiguously.  Slots behind a run's last event are replayed like events: their k is never read
+// (pix = 0xFFFF there) and the state they leave goes nowhere (the next record has its own start state).
+// Every 16 slots in use of a tile are one record of one run (runs start on multiples of REC), so the records of a tile
+// are simply its slot groups [0, tile_slots / REC): a wave's loads and stores cover consecutive groups of a tile, whatever
+// the chains look like (in chain order, content with short runs -- noise: one record per tile and context -- had every
+// lane on a cache line of its own: 1.45 ms per 64 noise frames against 0.24 on S1).  A workgroup takes ASSIGN_TILES
+// consecutive (plane, tile) items of the slice and spreads their groups over its lanes.
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t ASSIGN_TILES = 8;
 template <typename ET>
 __global__ __launch_bounds__(256) void k_assign3(const ET *__restrict__ ev, const uint4 *__restrict__ state16,
-                                                 const uint32_t *__restrict__ slice_nrec, uint8_t *__restrict__ kq) {
-    const uint32_t n = *slice_nrec;
-    const uint32_t stride = gridDim.x * 256;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const uint4 st = state16[i];
+                                                 const uint32_t *__restrict__ tile_slots, uint8_t *__restrict__ kq, uint32_t tile_begin,
+                                                 uint32_t slice_tiles, uint32_t sort_tiles, uint32_t tile_groups, uint32_t nitems) {
+    uint32_t first[ASSIGN_TILES + 1], base[ASSIGN_TILES];  // (uniform: scalar registers)
+    first[0] = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < ASSIGN_TILES; j++) {
+        const uint32_t item = blockIdx.x * ASSIGN_TILES + j;
+        uint32_t n = 0;
+        base[j] = 0;
+        if (item < nitems) {
+            const uint32_t plane = item / slice_tiles, tile = tile_begin + item % slice_tiles;
+            const uint32_t pt = plane * sort_tiles + tile;
+            n = min(tile_slots[pt] / REC, tile_groups);
+            base[j] = pt * tile_groups;
+        }
+        first[j + 1] = first[j] + n;
+    }
+    for (uint32_t i = threadIdx.x; i < first[ASSIGN_TILES]; i += 256) {
+        uint32_t rec = base[0] + i;
+#pragma unroll
+        for (uint32_t j = 1; j < ASSIGN_TILES; j++) rec = i >= first[j] ? base[j] + (i - first[j]) : rec;
+        const uint4 st = state16[rec];
         RecEvents<ET> e;
-        load_record(ev, st.w, e);
+        load_record(ev, rec, e);
         EstKeys est;
         est.set(st.x & 0xFFFFu, st.x >> 16, st.y & 0xFFFFu, st.y >> 16, st.z & 0xFFFFu, st.z >> 16);
         uint32_t kw[4];
@@ -562,19 +584,19 @@ __global__ __launch_bounds__(256) void k_assign3(const ET *__restrict__ ev, cons
             for (uint32_t b = 0; b < 4; b++) kk |= est.step(record_event(e, d * 4 + b)) << (8u * b);
             kw[d] = kk ^ 0x07070707u;  // 7 - (7 - k) in every byte
         }
-        *reinterpret_cast<uint4 *>(kq + (uint64_t)st.w * REC) = make_uint4(kw[0], kw[1], kw[2], kw[3]);
+        *reinterpret_cast<uint4 *>(kq + (uint64_t)rec * REC) = make_uint4(kw[0], kw[1], kw[2], kw[3]);
     }
 }
 
 template <typename ET>
-void launch_assign3(hipStream_t s, const ET *ev, const ChainSlice &cs, uint8_t *kq, const Geometry &g) {
-    // persistent: eight workgroups of four waves per CU stride over the records (fewer if there cannot be that many)
-    const uint64_t max_rec = (uint64_t)g.nplanes * g.sort_tiles * (tile_cap_max(g.nctx, g.npix) / REC);
-    const uint32_t wgs = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cdiv_u(max_rec, 256), 1u), 256u * 8u);
-    FELICS_LAUNCH((k_assign3<ET>), dim3(wgs), dim3(256), s, ev, cs.state16, cs.nrec, kq);
+void launch_assign3(hipStream_t s, const TileLocal<ET> &tl, const uint4 *state16, const Geometry &g, uint32_t tile_begin, uint32_t tile_end) {
+    if (tile_end <= tile_begin || g.nplanes == 0) return;
+    const uint32_t slice_tiles = tile_end - tile_begin, nitems = slice_tiles * g.nplanes;
+    FELICS_LAUNCH((k_assign3<ET>), dim3(cdiv_u(nitems, ASSIGN_TILES)), dim3(256), s, tl.ev, state16, tl.tile_slots, tl.kq, tile_begin, slice_tiles,
+                  g.sort_tiles, tl.cap / REC, nitems);
 }
-template void launch_assign3<uint8_t>(hipStream_t, const uint8_t *, const ChainSlice &, uint8_t *, const Geometry &);
-template void launch_assign3<uint16_t>(hipStream_t, const uint16_t *, const ChainSlice &, uint8_t *, const Geometry &);
+template void launch_assign3<uint8_t>(hipStream_t, const TileLocal<uint8_t> &, const uint4 *, const Geometry &, uint32_t, uint32_t);
+template void launch_assign3<uint16_t>(hipStream_t, const TileLocal<uint16_t> &, const uint4 *, const Geometry &, uint32_t, uint32_t);
 
 // Two-pass pack only (exact placement after a slot overflow, FELICS_TWO_PASS, or after a look-back gave up): k from the
 // tiles' slots to a byte per pixel, k_map[plane * npix + tile * SORT_TILE + pix[slot]] = kq[slot].

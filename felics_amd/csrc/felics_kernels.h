@@ -107,20 +107,21 @@ template <typename T, typename ET>
 void launch_front(hipStream_t s, const T *planes, const TileLocal<ET> &tl, const Geometry &g, uint32_t tile_begin, uint32_t tile_end,
                   uint32_t *flags, uint32_t mode);
 
-// The chain stage of one slice: records [0, *nrec) of the slice's region of desc / state16.
+// The chain stage of one slice: records [0, *nrec) of the slice's region of desc.
 struct ChainSlice {
     uint2 *desc;           // [rec] {record's first slot / REC (over the whole sub-batch), events in it}: chain order
     uint2 *chain_seg;      // [chain] {first record, records} of the chain in this slice
     uint32_t *nrec;        // records of the slice (device counter, zeroed per sub-batch)
-    uint4 *state16;        // [rec] {S0 | S1 << 16, S2 | S3 << 16, S4 | S5 << 16, first slot / REC}: the estimator's state at the record's first event
+    uint4 *state16;        // [slot / REC, over the whole sub-batch: the same array for every slice] {S0 | S1 << 16, S2 | S3 << 16, S4 | S5 << 16, slot / REC}: the estimator's state at the record's first event
 };
 void launch_enum(hipStream_t s, const uint32_t *runtab, const ChainSlice &cs, const Geometry &g, uint32_t tile_begin, uint32_t tile_end,
                  uint32_t cap);
 // chain_state: 8 words per chain (zeroed per sub-batch): the state behind the chain's last event so far
 template <typename ET>
 void launch_spine3(hipStream_t s, const ET *ev, const ChainSlice &cs, uint32_t *chain_state, uint32_t *flags, const Geometry &g);
+// k of the events of the tiles [tile_begin, tile_end) of every plane, from the states k_spine3 left
 template <typename ET>
-void launch_assign3(hipStream_t s, const ET *ev, const ChainSlice &cs, uint8_t *kq, const Geometry &g);
+void launch_assign3(hipStream_t s, const TileLocal<ET> &tl, const uint4 *state16, const Geometry &g, uint32_t tile_begin, uint32_t tile_end);
 // two-pass pack: k from the tiles' slots to a byte per pixel
 void launch_k_to_pixels_tl(hipStream_t s, const uint8_t *kq, const uint16_t *pix, const uint32_t *tile_slots, uint32_t cap, uint8_t *k_map,
                            const Geometry &g);

@@ -120,7 +120,7 @@ static int run_case(const char *name, const std::vector<T> &planes_h, uint32_t W
     for (int q = 0; q <= nslices; q++) bounds[q] = (uint32_t)((uint64_t)g.sort_tiles * q / nslices);
     auto slice_of = [&](int q) {
         const size_t r0 = (size_t)bounds[q] * nplanes * (cap / REC);
-        return ChainSlice{d_desc + r0, d_seg + (size_t)q * nchains, d_nrec + q, d_state + r0};
+        return ChainSlice{d_desc + r0, d_seg + (size_t)q * nchains, d_nrec + q, d_state};
     };
     hipStream_t s = nullptr;
     for (int q = 0; q < nslices; q++) {
@@ -128,7 +128,7 @@ static int run_case(const char *name, const std::vector<T> &planes_h, uint32_t W
         if (bounds[q + 1] == bounds[q]) continue;
         launch_enum(s, d_runtab, slice_of(q), g, bounds[q], bounds[q + 1], cap);
         launch_spine3<ET>(s, d_ev, slice_of(q), d_cstate, d_flags, g);
-        launch_assign3<ET>(s, d_ev, slice_of(q), d_kq, g);
+        launch_assign3<ET>(s, tl, d_state, g, bounds[q], bounds[q + 1]);
     }
     CK(hipDeviceSynchronize());
     std::vector<ET> ev(slots);
@@ -203,7 +203,7 @@ static int run_case(const char *name, const std::vector<T> &planes_h, uint32_t W
                         const uint32_t want_cnt = cnt[t][c] - j * REC < REC ? cnt[t][c] - j * REC : REC;
                         if (desc[ri].x != want_rec) fail("desc.rec", chain, ri, desc[ri].x, want_rec);
                         if (desc[ri].y != want_cnt) fail("desc.cnt", chain, ri, desc[ri].y, want_cnt);
-                        const uint4 st = state[ri];
+                        const uint4 st = state[want_rec];
                         const uint32_t got[6] = {st.x & 0xFFFFu, st.x >> 16, st.y & 0xFFFFu, st.y >> 16, st.z & 0xFFFFu, st.z >> 16};
                         for (int k = 0; k < 6; k++)
                             if (got[k] != est.s[k]) fail("state", chain, ri * 8 + k, got[k], est.s[k]);

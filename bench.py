@@ -518,8 +518,13 @@ def main():
                         # share of cheap instructions from the shipped code object) -- an additive figure: mixed streams cost more
                         # (valu_rate_mixed_streams.txt), so it is a lower bound of the issue time
                         weighted_ns = tj.get("_valu_weighted_ns_per_step")
+                        # Two ceilings, both reported: the guide's issue rate (a wave64 VALU instruction every 2 cycles per SIMD:
+                        # 1024 SIMDs x 2.4 GHz / 2 = 1.23 T/s -- what packed / dual-issued fp32 reaches) and the rate integer
+                        # instructions were measured at on this chip (4 cycles: 0.595 T/s for the 1.7 ns class)
                         valu = {"wave_insts_per_step": int(insts), "issue_peak_per_s": 0.595e12, "issue_peak": "measured, profiles/r04/valu_rate.txt (1.7 ns class)",
                                 "frac_of_issue_peak": round(insts / 0.595e12 / (ms_per_step * 1e-3), 4),
+                                "datasheet_issue_peak_per_s": 1.2288e12,
+                                "frac_of_datasheet_issue_peak": round(insts / 1.2288e12 / (ms_per_step * 1e-3), 4),
                                 "weighted_issue_ms_per_step": None if not weighted_ns else round(weighted_ns / 1024 / 1e6, 4),
                                 "weighted_frac_of_step": None if not weighted_ns else round(weighted_ns / 1024 / 1e6 / ms_per_step, 4)}
             roofline = {"bound": "hbm", "kernel": kernel_of(dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,

@@ -895,8 +895,7 @@ int felics_ctx_create(int device, felics_ctx **out) {
     if (const char *e = getenv("FELICS_SCATTER")) ctx->scatter_ballot = !strcmp(e, "ballot");
     ctx->test_tile_cap = getenv("FELICS_TEST_TILE_CAP") != nullptr;
     ctx->test_scatter_order = getenv("FELICS_TEST_SCATTER_ORDER") != nullptr;
-    ctx->own_tails = getenv("FELICS_OWN_TAILS") != nullptr;
-    ctx->pack_tickets = ctx->own_tails && atoi(getenv("FELICS_OWN_TAILS")) != 2;
+    ctx->pack_tickets = ctx->own_tails = getenv("FELICS_OWN_TAILS") != nullptr;
     ctx->serial = getenv("FELICS_SERIAL") != nullptr;
     ctx->test_timeout = getenv("FELICS_TEST_TIMEOUT") != nullptr;
     if (const char *e = getenv("FELICS_SLICES")) ctx->slices_blocking = std::max(1, std::min(atoi(e), SLICES));
@@ -905,19 +904,13 @@ int felics_ctx_create(int device, felics_ctx **out) {
     if (const char *e = getenv("FELICS_TIMEOUT_S")) ctx->timeout_s = std::max(1, atoi(e));
     bool ok = hipSetDevice(device) == hipSuccess;
     // Oldest work first: the spine (the one sequential chain) and the tail, which finishes the submission that is
-    // furthest along, go before the front (histogram and scatter of the submission that has just started).  Measured with
-    // two submissions in flight: 4.11 / 4.13 ms per step against 4.24 / 4.19 with the front preferred (round 1's choice)
-    // and 4.12 / 4.17 with only the tail preferred; blocking calls do not care.
+    // furthest along, go before the front (classification and event sort of the submission that has just started).  Measured
+    // with two submissions in flight: 4.11 / 4.13 ms per step against 4.24 / 4.19 with the front preferred (round 1's choice)
+    // and 4.12 / 4.17 with only the tail preferred; round 5, all eight combinations of high / low for spine, front and tail:
+    // 2.53-2.65 ms, the differences inside the run-to-run spread (profiles/r05/experiments.txt); blocking calls do not care.
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);  // numerically: low >= high
     int prio_spine = prio_high, prio_front = prio_low, prio_tail = prio_high;
-    if (const char *e = getenv("FELICS_EXP_PRIO")) {  // (tuning experiments: three digits, 1 = high, for spine / front / tail)
-        if (strlen(e) >= 3) {
-            prio_spine = e[0] == '1' ? prio_high : prio_low;
-            prio_front = e[1] == '1' ? prio_high : prio_low;
-            prio_tail = e[2] == '1' ? prio_high : prio_low;
-        }
-    }
     for (int li = 0; li < ctx->nlanes; li++) {
         Lane &l = ctx->lanes[li];
         ok = ok && hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio_spine) == hipSuccess;

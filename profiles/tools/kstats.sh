@@ -20,7 +20,7 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if "felics" in r["Name"]]
 with open(sys.argv[2], "w") as o:
     o.write("kernel,calls,total_ns,average_ns,percent\n")
     for r in rows:
-        name = r["Name"].split("felics::")[-1].split("(")[0]
+        name = r["Name"].split("felics::")[1].split("(")[0]
         o.write("%s,%s,%s,%s,%s\n" % (name, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
 print(open(sys.argv[2]).read())
 PY

@@ -173,9 +173,6 @@ extern "C" __attribute__((visibility("default"))) int felics_debug_spine_stamps(
 #define SP3_STAMP(i)
 #endif
 
-#ifndef FELICS_SP3_EXP
-#define FELICS_SP3_EXP 0
-#endif
 constexpr uint32_t SP3_ROW = REC * 3 + 1;   // dwords per record in pref (odd: the helper's 64 rows start in different banks)
 constexpr uint32_t SP3_CROW = 9;            // dwords per row of cumT (odd, likewise)
 constexpr uint32_t SP3_MULTI_MIN = 3;       // windows

@@ -1,6 +1,7 @@
 """Randomised parity run of the GPU encoder against the oracle (tests/oracle_lib): shapes from 1x1 up, widths around the kernels'
 trip and tile sizes, flat / noise / gradient / synthetic content, gray8 and RGB8, batches of 1-5 frames, blocking calls and queued
-submissions, both event sorts.  Runs ON THE GPU BOX from the repository root:  python3 profiles/tools/fuzz_encode.py [seconds] [seed]
+submissions; three contexts: the default, one that ranks events with ballots (FELICS_SCATTER=ballot), one whose first batch overflows its
+tiles and which sizes them for the worst case from then on (FELICS_TEST_TILE_CAP).  Runs ON THE GPU BOX from the repository root:  python3 profiles/tools/fuzz_encode.py [seconds] [seed]
 Test infrastructure: the oracle is the checker here, as in tests/."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,11 +15,12 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 oracle = oracle_lib.load()
 encs = {}
-for mode in ("auto", "sorted", "ballot"):
-    if mode != "auto":
-        os.environ["FELICS_SCATTER"] = mode
+MODES = {"default": {}, "ballot": {"FELICS_SCATTER": "ballot"}, "worst-case tiles": {"FELICS_TEST_TILE_CAP": "1"}}
+for mode, env in MODES.items():
+    os.environ.update(env)
     encs[mode] = felics_amd.Encoder(0)
-    os.environ.pop("FELICS_SCATTER", None)
+    for k in env:
+        del os.environ[k]
 special_w = [1, 2, 3, 4, 5, 63, 64, 65, 127, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 4095, 4096, 4097]
 
 
@@ -51,7 +53,7 @@ while time.time() - t0 < budget:
     kind = int(rng.integers(0, 5))
     frames = [content(kind, h, w, c, f) for f in range(n)]
     want = [oracle.compress(f) for f in frames]
-    mode = ("auto", "sorted", "ballot")[int(rng.integers(0, 3))]
+    mode = list(MODES)[int(rng.integers(0, 3))]
     enc = encs[mode]
     if rng.random() < 0.5:
         got = enc.compress_batch(frames)
@@ -72,7 +74,7 @@ while time.time() - t0 < budget:
 st = {m: e.stats() for m, e in encs.items()}
 print("%d cases (%d frames) in %.0f s, all streams equal to the oracle's; by mode %s" % (cases, frames_done, time.time() - t0, by_mode))
 for m, s in st.items():
-    print("  %-6s submissions %d, sorted event sorts %d, scatter fallbacks %d, look-back fallbacks %d, slot overflows %d"
-          % (m, s["submissions"], s["sorted_event_sorts"], s["scatter_fallbacks"], s["lookback_fallbacks"], s["slot_overflows"]))
+    print("  %-16s submissions %d, ranked by LDS atomics %d, order-check fallbacks %d, tile overflows %d, look-back fallbacks %d, slot overflows %d"
+          % (m, s["submissions"], s["sorted_event_sorts"], s["scatter_fallbacks"], s["tile_overflows"], s["lookback_fallbacks"], s["slot_overflows"]))
 for e in encs.values():
     e.close()

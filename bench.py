@@ -447,9 +447,36 @@ def main():
                    "MPix_s_per_stream": round(npix / big_s / 1e6, 3), "form": "64 streams per wave (lane = stream)"}
         except (torch.OutOfMemoryError, felics_amd.FelicsError):  # no room for 34 GB of frames (or for the library's tables): no large-batch figure
             big = None
+        # the same form on RGB8 streams (1920x1080 frames: 4096 4K RGB frames and their int16 planes would not fit): three planes
+        # per lane from one bit reader
+        big_rgb = None
+        try:
+            from felics_amd import synth_torch as st2
+
+            WR, HR, FR, NR = 1920, 1080, 16, 4096
+            fr = torch.stack([st2.rgb8(WR, HR, f, device=dev) for f in range(FR)])
+            capr = int(FR * WR * HR * 3 * 1.25) + (1 << 20)
+            d_or = torch.empty(capr, dtype=torch.uint8, device=dev)
+            offr, lenr = enc.compress_batch_device(fr.data_ptr(), FR, WR, HR, 1, 0, d_or.data_ptr(), capr)
+            o_r = np.array([offr[i % FR] for i in range(NR)], dtype=np.uint64)
+            l_r = np.array([lenr[i % FR] for i in range(NR)], dtype=np.uint64)
+            d_r = torch.empty((NR, HR, WR, 3), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _, str_ = enc.decompress_batch_device(d_or.data_ptr(), o_r, l_r, d_r.data_ptr(), d_r.numel())
+            torch.cuda.synchronize()
+            rgb_s = time.perf_counter() - t1
+            if not (str_ == 0).all() or not bool((d_r[NR - 1] == fr[(NR - 1) % FR]).all()) or not bool((d_r[FR + 1] == fr[1]).all()):
+                raise SystemExit("GPU decoder (64 RGB streams per wave): pixels differ from the frames that were encoded")
+            del d_r, d_or, fr
+            big_rgb = {"streams": NR, "frame": "%dx%d RGB8" % (WR, HR), "gpu_MPix_s": round(NR * WR * HR / rgb_s / 1e6, 1),
+                       "gpu_MSamples_s": round(3 * NR * WR * HR / rgb_s / 1e6, 1), "gpu_seconds_per_batch": round(rgb_s, 3),
+                       "form": "64 streams per wave (lane = stream), three planes per lane"}
+        except (torch.OutOfMemoryError, felics_amd.FelicsError):
+            big_rgb = None
         decode = {"gpu_MPix_s": round(F * npix / gpu_s / 1e6, 1), "gpu_seconds_per_batch": round(gpu_s, 3), "streams": F,
                   "gpu_note": "felics_decompress_batch_device: one wave per stream, %d streams = %d waves on 256 CUs" % (F, F),
-                  "large_batch": big,
+                  "large_batch": big, "large_batch_rgb": big_rgb,
                   "host_MPix_s_1_core": round(npix / one / 1e6, 1),
                   "host_MPix_s_%d_cores" % cores: round(len(sample) * npix / many / 1e6, 1),
                   "host_sample": "%d of the batch's streams, felics_decompress (C++)" % len(sample), "pixels_checked": True}

@@ -1353,16 +1353,16 @@ int felics_decompress_batch_device(felics_ctx *ctx, size_t n, const void *d_stre
     HIP_TRY(ctx, hipMemcpyAsync(d_off, offsets, n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_len, lens, n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(d_status, 0xFF, n * 4, s));
-    // hundreds of gray streams and more: 64 streams per wave (lane = stream); fewer, or RGB: one wave per stream
+    // hundreds of streams and more: 64 streams per wave (lane = stream); fewer: one wave per stream
     // (FELICS_TEST_DECODE_LANES=1 / =0 force one form whatever the batch: tests)
-    bool by_lane = planes == 1 && hdr.width >= 8 && n >= DECODE8_LANES_MIN_STREAMS;
-    if (const char *e = getenv("FELICS_TEST_DECODE_LANES")) by_lane = planes == 1 && hdr.width >= 8 && atoi(e) != 0;
+    bool by_lane = hdr.width >= 8 && n >= (planes == 3 ? DECODE8_LANES_MIN_STREAMS_RGB : DECODE8_LANES_MIN_STREAMS);
+    if (const char *e = getenv("FELICS_TEST_DECODE_LANES")) by_lane = hdr.width >= 8 && atoi(e) != 0;
     if (by_lane) {
-        const size_t tb = decode8_lanes_table_bytes((uint32_t)n);
+        const size_t tb = decode8_lanes_table_bytes((uint32_t)n, hdr.color_type);
         if ((rc = reserve(ctx, ctx->dec_lane_table, tb)) != 0) return fail_all(rc);
         HIP_TRY(ctx, hipMemsetAsync(ctx->dec_lane_table.p, 0, tb, s));
-        HIP_TRY(ctx, launch_decode8_lanes(s, (const uint8_t *)d_streams, d_off, d_len, (uint32_t)n, hdr.width, hdr.height, (uint8_t *)d_pixels,
-                                          (uint32_t *)ctx->dec_lane_table.p, d_status));
+        HIP_TRY(ctx, launch_decode8_lanes(s, (const uint8_t *)d_streams, d_off, d_len, (uint32_t)n, hdr.width, hdr.height, hdr.color_type,
+                                          (uint8_t *)d_pixels, d_planes, (uint32_t *)ctx->dec_lane_table.p, d_status));
     } else {
         HIP_TRY(ctx, launch_decode8(s, (const uint8_t *)d_streams, d_off, d_len, (uint32_t)n, hdr.width, hdr.height, hdr.color_type,
                                     (uint8_t *)d_pixels, d_planes, d_status));

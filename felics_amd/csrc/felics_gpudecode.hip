@@ -17,6 +17,7 @@
 // length check would fire), never with an out-of-bounds access: every read of the stream is bounded by its
 // length and every pixel by the image size.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "../../include/felics.h"
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(64) void k_decode8(const uint8_t *__restrict__ stre
 
 constexpr uint32_t DEC8L_HOT = 32;                 // contexts per stream in LDS: 64 x 32 x 12 B = 24 KB per wave
 constexpr uint32_t DEC8L_TABLE_DW = 256 * 3;       // dwords per stream in HBM: 256 contexts x three pairs of u16 counters
+constexpr uint32_t DEC8L_TABLE_DW_RGB = 512 * 3;   // per plane of an RGB stream (contexts 0 .. 510)
 
 namespace {
 
@@ -376,23 +378,58 @@ struct LaneReader {
     }
 };
 
-// four samples of a stream's own output image (unaligned dword; the image is this wave's to write and to read)
-__device__ __forceinline__ uint32_t read_back4(const uint8_t *p) {
+// four consecutive samples of a stream's own output plane (one unaligned load / store; the plane is this wave's to write and to read)
+template <typename ST>
+struct Four;
+template <>
+struct Four<uint8_t> {
     uint32_t v;
-    __builtin_memcpy(&v, p, 4);
-    return v;
-}
+    __device__ __forceinline__ void clear() { v = 0; }
+    __device__ __forceinline__ void load(const uint8_t *p) { __builtin_memcpy(&v, p, 4); }
+    __device__ __forceinline__ void store(uint8_t *p) const { __builtin_memcpy(p, &v, 4); }
+    __device__ __forceinline__ int get(uint32_t j) const { return (int)((v >> (8u * j)) & 0xFFu); }
+    __device__ __forceinline__ void set(uint32_t j, int s) { v |= (uint32_t)s << (8u * j); }  // (0 <= s <= 255, the field still zero)
+};
+template <>
+struct Four<int16_t> {
+    uint32_t lo, hi;  // (two named dwords: an array indexed by the sample's number went to scratch memory)
+    __device__ __forceinline__ void clear() { lo = hi = 0; }
+    __device__ __forceinline__ void load(const int16_t *p) {
+        uint32_t v[2];
+        __builtin_memcpy(v, p, 8);
+        lo = v[0];
+        hi = v[1];
+    }
+    __device__ __forceinline__ void store(int16_t *p) const {
+        const uint32_t v[2] = {lo, hi};
+        __builtin_memcpy(p, v, 8);
+    }
+    __device__ __forceinline__ int get(uint32_t j) const { return (int)(int16_t)(((j & 2u) ? hi : lo) >> (16u * (j & 1u))); }
+    __device__ __forceinline__ void set(uint32_t j, int s) {  // (the field still zero)
+        const uint32_t f = ((uint32_t)s & 0xFFFFu) << (16u * (j & 1u));
+        lo |= (j & 2u) ? 0u : f;
+        hi |= (j & 2u) ? f : 0u;
+    }
+};
 
 }  // namespace
 
+// RGB = false: gray8 streams, u8 frames straight to `out_base`.  RGB = true: the three planes of an RGB8 stream, one after the other from
+// the same bit reader (compression.rs:385-400), as int16 planes (image i at i * 3 * npix; k_ycocg8_to_rgb converts them): samples
+// -255 .. 255, contexts 0 .. 510, a zeroed table of its own per plane.  A counter still fits 16 bits: the Rice operand is at most 1024
+// (larger is the corrupt-stream exit), so counter 0 gains at most 1025 per event while counter 5 gains at least 38, i.e. at most 27.7 K
+// before the smallest counter passes 1024 and the row is halved -- below 56 K with the halved rest on top.
+template <bool RGB>
 __global__ __launch_bounds__(64) void k_decode8_lanes(const uint8_t *__restrict__ streams, const uint64_t *__restrict__ offsets,
                                                       const uint64_t *__restrict__ lens, uint32_t n, uint32_t W, uint32_t H,
-                                                      uint8_t *pixels, uint32_t *table, int *__restrict__ status) {
+                                                      void *out_base, uint32_t *table, int *__restrict__ status) {
+    using ST = typename std::conditional<RGB, int16_t, uint8_t>::type;
+    constexpr uint32_t NP = RGB ? 3u : 1u;
+    constexpr uint32_t TABLE_DW = RGB ? DEC8L_TABLE_DW_RGB : DEC8L_TABLE_DW;  // per plane
+    constexpr int LO_OK = RGB ? -255 : 0, HI_OK = 255;
     __shared__ uint32_t hot[DEC8L_HOT * 3 * 64];  // [context][pair of counters][lane]
     const uint32_t lane = lane_id();
     const uint32_t img = blockIdx.x * 64 + lane;
-    for (uint32_t i = lane; i < DEC8L_HOT * 3 * 64; i += 64) hot[i] = 0;  // KEstimator::new (the HBM rows arrive zeroed)
-    __builtin_amdgcn_wave_barrier();
     if (img >= n) return;
     const uint8_t *s = streams + offsets[img];
     const uint64_t slen = lens[img];
@@ -407,7 +444,7 @@ __global__ __launch_bounds__(64) void k_decode8_lanes(const uint8_t *__restrict_
         if (s[0] != 'F' || s[1] != 'L' || s[2] != 'C' || s[3] != 'S') rc = FELICS_E_INVALID_SIGNATURE;
         else if (s[4] > 1) rc = FELICS_E_INVALID_COLOR_TYPE;
         else if (s[5] > 1) rc = FELICS_E_INVALID_PIXEL_DEPTH;
-        else if (s[4] != 0 || s[5] != 0 || w != W || h != H) rc = FELICS_E_INVALID_DIMENSIONS;
+        else if (s[4] != (RGB ? 1 : 0) || s[5] != 0 || w != W || h != H) rc = FELICS_E_INVALID_DIMENSIONS;
     }
     if (rc != FELICS_OK) {  // nothing of this stream is decoded (its lane leaves; the others go on)
         status[img] = rc;
@@ -415,45 +452,47 @@ __global__ __launch_bounds__(64) void k_decode8_lanes(const uint8_t *__restrict_
     }
     LaneReader br;
     br.init(s + FELICS_HEADER_BYTES, slen - FELICS_HEADER_BYTES);
-    const int32_t p0 = (int32_t)br.get(32), p1 = (int32_t)br.get(32);  // compression.rs:166-167
-    if (br.failed()) rc = FELICS_E_IO;
-    if (npix == 0 || rc != FELICS_OK) {
-        status[img] = rc;
-        return;
-    }
-    uint32_t *tab = table + (uint64_t)img * DEC8L_TABLE_DW;
-    uint8_t *out = pixels + (uint64_t)img * npix;
     uint32_t *myhot = hot + lane;
+    for (uint32_t plane = 0; plane < NP; plane++) {
+    for (uint32_t i = 0; i < DEC8L_HOT * 3; i++) myhot[i * 64] = 0;  // KEstimator::new (the HBM rows arrive zeroed); a lane's own column
+    const int32_t p0 = (int32_t)br.get(32), p1 = (int32_t)br.get(32);  // compression.rs:166-167
+    if (br.failed() && rc == FELICS_OK) rc = FELICS_E_IO;
+    if (npix == 0) continue;
+    uint32_t *tab = table + ((uint64_t)img * NP + plane) * TABLE_DW;
+    ST *out = reinterpret_cast<ST *>(out_base) + ((uint64_t)img * NP + plane) * npix;
     // (x, y) and everything derived from them alone is wave-uniform: every stream has the same shape
     int left = 0, left2 = 0;
-    uint32_t up4 = 0, up4_next = 0, out4 = 0;
-    uint32_t out_of_range = 0;  // OR of every sample as decoded: above 255 if one did not fit eight bits (negative ones included)
+    Four<ST> up4, up4_next, out4;
+    up4.clear();
+    up4_next.clear();
+    out4.clear();
+    uint32_t out_of_range = 0;  // gray: OR of every sample as decoded (above 255 if one did not fit); RGB: nonzero if one was outside LO_OK .. HI_OK
     int first_col2 = 0;
     for (uint32_t y = 0; y < H; y++) {
-      uint8_t *row = out + (uint64_t)y * W;  // this row of the stream's image, and the one above it
-      const uint8_t *prow = row - W;
+      ST *row = out + (uint64_t)y * W;  // this row of the stream's plane, and the one above it
+      const ST *prow = row - W;
       if (y > 0) {
-          up4 = read_back4(prow);                   // row above, samples 0 .. 3 (later groups are asked for four samples ahead)
-          if (4 < W) up4_next = read_back4(prow + 4);
+          up4.load(prow);                   // row above, samples 0 .. 3 (later groups are asked for four samples ahead)
+          if (4 < W) up4_next.load(prow + 4);
           // second neighbour of a row's first pixel (misc.rs:14-23): two rows up, or above-right in row 1
-          first_col2 = y >= 2 ? (int)prow[-(int64_t)W] : (W > 1 ? (int)((up4 >> 8) & 0xFFu) : 0);
+          first_col2 = y >= 2 ? (int)prow[-(int64_t)W] : (W > 1 ? up4.get(1) : 0);
       }
       for (uint32_t x = 0; x < W; x++) {
         const uint32_t xs = x & 3u;
         if (xs == 0 && y > 0 && x != 0) {
             up4 = up4_next;
-            if (x + 4 < W) up4_next = read_back4(prow + x + 4);
+            if (x + 4 < W) up4_next.load(prow + x + 4);
         }
         int pv;
         if (y == 0 && x < 2) {
             pv = x == 0 ? p0 : p1;
         } else {
-            const int above = (int)((up4 >> (8u * xs)) & 0xFFu);
+            const int above = up4.get(xs);
             const bool row0 = y == 0, col0 = x == 0 && !row0;
             const int v1 = col0 ? above : left;
             const int v2 = col0 ? first_col2 : (row0 ? left2 : above);
             const int hi = max(v1, v2), lo = min(v1, v2);
-            const uint32_t ctx = (uint32_t)(hi - lo);  // <= 255: every sample kept is in range
+            const uint32_t ctx = (uint32_t)(hi - lo);  // <= 255 (510): every sample kept is in range
             // The context's row for every lane, whether its pixel turns out to be an event or not (no divergence, and the LDS
             // round trip runs beside the arithmetic below): three pairs of 16-bit counters; hot contexts from LDS.
             const bool is_hot = ctx < DEC8L_HOT;
@@ -530,22 +569,28 @@ __global__ __launch_bounds__(64) void k_decode8_lanes(const uint8_t *__restrict_
             }
             pv = in_range ? pv_in : (above_flag ? hi + (int)e + 1 : lo - (int)e - 1);
         }
-        // try_into::<u8>() would fail on anything outside 0 .. 255: remembered (two instructions per pixel instead of eight) and
-        // reported at the end of the row; the sample is cut to eight bits so that a failed stream's contexts stay inside the table
-        out_of_range |= (uint32_t)pv;
-        pv &= 255;
-        out4 |= (uint32_t)pv << (8u * xs);
+        // try_into::<u8>() (for RGB: the estimator's context bound) would fail on anything outside LO_OK .. HI_OK: remembered and
+        // reported at the end of the row; the sample is cut into the range so that a failed stream's contexts stay inside the table
+        if (RGB) {
+            out_of_range |= (uint32_t)(pv - LO_OK) > (uint32_t)(HI_OK - LO_OK) ? 1u : 0u;
+            pv = min(max(pv, LO_OK), HI_OK);
+        } else {
+            out_of_range |= (uint32_t)pv;  // (two instructions per pixel: above 255 if one did not fit eight bits, negative ones included)
+            pv &= 255;
+        }
+        out4.set(xs, pv);
         left2 = left;
         left = pv;
-        if (xs == 3u) {  // four samples complete: one (unaligned) dword to the stream's image
-            __builtin_memcpy(row + (x - 3u), &out4, 4);
-            out4 = 0;
+        if (xs == 3u) {  // four samples complete: one (unaligned) store to the stream's plane
+            out4.store(row + (x - 3u));
+            out4.clear();
         } else if (x + 1 == W) {  // the last one to three samples of a row
-            for (uint32_t j = 0; j <= xs; j++) row[(x - xs) + j] = (uint8_t)(out4 >> (8u * j));
-            out4 = 0;
+            for (uint32_t j = 0; j <= xs; j++) row[(x - xs) + j] = (ST)out4.get(j);
+            out4.clear();
         }
       }
-      if (rc == FELICS_OK) rc = br.failed() ? FELICS_E_IO : (out_of_range > 255u ? FELICS_E_INVALID_VALUE : FELICS_OK);
+      if (rc == FELICS_OK) rc = br.failed() ? FELICS_E_IO : ((RGB ? out_of_range != 0 : out_of_range > 255u) ? FELICS_E_INVALID_VALUE : FELICS_OK);
+    }
     }
     if (br.failed() && rc == FELICS_OK) rc = FELICS_E_IO;  // (whatever else: it was decoding padding)
     status[img] = rc;
@@ -795,13 +840,21 @@ hipError_t launch_decode16(hipStream_t s, const uint8_t *streams, const uint64_t
     return hipGetLastError();
 }
 
-size_t decode8_lanes_table_bytes(uint32_t n) { return (size_t)n * DEC8L_TABLE_DW * 4; }
+size_t decode8_lanes_table_bytes(uint32_t n, uint32_t color) { return (size_t)n * (color ? 3u * DEC8L_TABLE_DW_RGB : DEC8L_TABLE_DW) * 4; }
 
-// lane = stream (gray8, W >= 8); `table` = decode8_lanes_table_bytes(n) bytes, all zero
+// lane = stream (gray8 or RGB8, W >= 8); `table` = decode8_lanes_table_bytes(n, color) bytes, all zero; RGB: `planes` takes the int16
+// planes (n * 3 * W * H), `pixels` the converted frames
 hipError_t launch_decode8_lanes(hipStream_t s, const uint8_t *streams, const uint64_t *offsets, const uint64_t *lens, uint32_t n,
-                                uint32_t W, uint32_t H, uint8_t *pixels, uint32_t *table, int *status) {
+                                uint32_t W, uint32_t H, uint32_t color, uint8_t *pixels, int16_t *planes, uint32_t *table, int *status) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_decode8_lanes, dim3((n + 63) / 64), dim3(64), 0, s, streams, offsets, lens, n, W, H, pixels, table, status);
+    if (!color) {
+        hipLaunchKernelGGL(k_decode8_lanes<false>, dim3((n + 63) / 64), dim3(64), 0, s, streams, offsets, lens, n, W, H, (void *)pixels, table, status);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_decode8_lanes<true>, dim3((n + 63) / 64), dim3(64), 0, s, streams, offsets, lens, n, W, H, (void *)planes, table, status);
+    const uint64_t npix = (uint64_t)W * H;
+    const uint32_t bx = (uint32_t)std::min<uint64_t>((npix + 255) / 256, 1024u);
+    if (bx) hipLaunchKernelGGL(k_ycocg8_to_rgb, dim3(bx, n), dim3(256), 0, s, planes, pixels, (uint32_t)npix, status);
     return hipGetLastError();
 }
 

@@ -211,13 +211,15 @@ size_t decode16_table_bytes(uint32_t n);
 hipError_t launch_decode16(hipStream_t s, const uint8_t *streams, const uint64_t *offsets, const uint64_t *lens, uint32_t n,
                            uint32_t W, uint32_t H, uint32_t color, uint16_t *pixels, int32_t *planes, uint32_t *table,
                            uint32_t epoch0, int *status);
-// The same for large batches of gray streams (felics_gpudecode.hip, k_decode8_lanes): 64 streams per wave, lane = stream; needs W >= 8
-// and a zeroed table of decode8_lanes_table_bytes(n) bytes (3 KB per stream: the estimator rows that do not live in LDS).
+// The same for large batches of 8-bit streams, gray or RGB (felics_gpudecode.hip, k_decode8_lanes): 64 streams per wave, lane = stream;
+// needs W >= 8 and a zeroed table of decode8_lanes_table_bytes(n, color) bytes (3 KB per gray stream, 18 KB per RGB stream: the
+// estimator rows that do not live in LDS); RGB: `planes` as for launch_decode8.
 constexpr uint32_t DECODE8_LANES_MIN_STREAMS = 1536;  // measured (profiles/r04/decode_scaling.txt): one wave per stream saturates at ~2.3 GPix/s from ~1000
                                                        // streams, a lane decodes 1.47 MPix/s whatever the batch: the forms cross at ~1500 streams
-size_t decode8_lanes_table_bytes(uint32_t n);
+constexpr uint32_t DECODE8_LANES_MIN_STREAMS_RGB = 2048;  // RGB8 (profiles/r05/decode_scaling_rgb.txt, 1080p frames): 0.88 against 0.94 GPix/s at 2048 streams, 0.97 / 1.88 at 4096
+size_t decode8_lanes_table_bytes(uint32_t n, uint32_t color);
 hipError_t launch_decode8_lanes(hipStream_t s, const uint8_t *streams, const uint64_t *offsets, const uint64_t *lens, uint32_t n,
-                                uint32_t W, uint32_t H, uint8_t *pixels, uint32_t *table, int *status);
+                                uint32_t W, uint32_t H, uint32_t color, uint8_t *pixels, int16_t *planes, uint32_t *table, int *status);
 hipError_t launch_decode8(hipStream_t s, const uint8_t *streams, const uint64_t *offsets, const uint64_t *lens, uint32_t n,
                           uint32_t W, uint32_t H, uint32_t color, uint8_t *pixels, int16_t *planes, int *status);
 

@@ -1,6 +1,6 @@
 """GPU decoder throughput by batch size, both forms (one wave per stream / 64 streams per wave): runs ON THE GPU BOX.
 
-    python3 profiles/tools/decode_scale.py [--kind S1] [--sizes 64,256,1024,4096]
+    python3 profiles/tools/decode_scale.py [--kind S1] [--sizes 64,256,1024,4096] [--rgb]
 
 The streams are the GPU encoder's of 64 synthetic 4K gray8 frames, referenced repeatedly for the larger batches (the decoder
 reads them through offsets / lens; every decoded image has a buffer of its own).  Prints GPix/s per form and batch size, the
@@ -17,13 +17,19 @@ from felics_amd import synth_torch, api
 ap = argparse.ArgumentParser()
 ap.add_argument("--kind", default="S1")
 ap.add_argument("--sizes", default="64,256,1024,4096")
+ap.add_argument("--rgb", action="store_true", help="RGB8 streams of 1920x1080 frames (a 4K RGB batch of 4096 would need 300 GB for frames + planes)")
 a = ap.parse_args()
-W, H, F = 3840, 2160, 64
+W, H, F = (1920, 1080, 64) if a.rgb else (3840, 2160, 64)
+C = 3 if a.rgb else 1
 dev = torch.device("cuda", 0)
-frames = torch.stack([synth_torch.gray8(W, H, f, a.kind, device=dev) for f in range(F)])
-d_out = torch.empty(int(F * W * H * 1.25) + (1 << 20), dtype=torch.uint8, device=dev)
+if a.rgb:
+    from felics_amd import synth
+    frames = torch.stack([torch.from_numpy(synth.rgb8(W, H, f)) for f in range(F)]).to(dev)
+else:
+    frames = torch.stack([synth_torch.gray8(W, H, f, a.kind, device=dev) for f in range(F)])
+d_out = torch.empty(int(F * W * H * C * 1.25) + (1 << 20), dtype=torch.uint8, device=dev)
 enc = felics_amd.Encoder(0)
-offs, lens = enc.compress_batch_device(frames.data_ptr(), F, W, H, 0, 0, d_out.data_ptr(), d_out.numel())
+offs, lens = enc.compress_batch_device(frames.data_ptr(), F, W, H, 1 if a.rgb else 0, 0, d_out.data_ptr(), d_out.numel())
 host = d_out[: int(offs[-1] + lens[-1])].cpu().numpy()
 sample = [host[int(offs[i]): int(offs[i] + lens[i])].tobytes() for i in range(16)]
 from concurrent.futures import ThreadPoolExecutor
@@ -38,7 +44,7 @@ res = {}
 for n in [int(x) for x in a.sizes.split(",")]:
     o = np.array([offs[i % F] for i in range(n)], dtype=np.uint64)
     l = np.array([lens[i % F] for i in range(n)], dtype=np.uint64)
-    d_px = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+    d_px = torch.empty((n, H, W, C) if a.rgb else (n, H, W), dtype=torch.uint8, device=dev)
     for form in ("0", "1"):
         os.environ["FELICS_TEST_DECODE_LANES"] = form
         best = None

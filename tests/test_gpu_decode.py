@@ -333,9 +333,79 @@ def test_lane_decoder_corrupt_streams(enc, oracle):
             assert (host[i * img.size:(i + 1) * img.size].reshape(img.shape) == want).all(), i
 
 
+def test_lane_decoder_rgb(enc, oracle):
+    """The lane form on RGB8 streams (three planes from one bit reader per lane, int16 Y / Co / Cg planes, contexts up to 510, a table
+    per plane): shapes with W >= 8 and odd widths, noise (every context; Co / Cg at their extremes), flat, checker, primaries with
+    spikes, synthetic frames, a ragged last wave -- against the original pixels and the host decoder's; then the corrupt-stream list:
+    every stream gets a status, good streams beside bad ones in the same wave decode intact."""
+    import felics_amd
+    import torch
+    from felics_amd import synth
+
+    rng = np.random.default_rng(77)
+    with _forced("1"):
+        for w, h in [(8, 1), (9, 3), (11, 2), (63, 5), (64, 4), (65, 9), (100, 40), (124, 74), (1447, 8), (320, 240)]:
+            imgs = [rng.integers(0, 256, size=(h, w, 3)).astype(np.uint8) for _ in range(3)]
+            g = (np.add.outer(np.arange(h), np.arange(w)) // 2 % 256).astype(np.uint8)
+            imgs.append(np.stack([g, g[::-1], 255 - g], -1).copy())
+            imgs.append(np.full((h, w, 3), (255, 0, 255), np.uint8))                                  # Co, Cg at their extremes
+            chk = ((np.add.outer(np.arange(h), np.arange(w)) & 1) * 255).astype(np.uint8)
+            imgs.append(np.stack([chk, 255 - chk, chk], -1).copy())                                   # full-scale swings in every plane
+            spikes = rng.integers(100, 104, size=(h, w, 3)).astype(np.uint8)
+            spikes[rng.random((h, w)) < 0.02] = (255, 0, 0)
+            spikes[rng.random((h, w)) < 0.02] = (0, 255, 255)
+            imgs.append(spikes)
+            imgs.append(synth.rgb8(w, h, 2))
+            streams = [oracle.compress(im) for im in imgs]
+            hdr, back = _decode_batch(enc, streams, (h, w, 3), np.uint8)
+            assert (hdr.width, hdr.height, hdr.color_type) == (w, h, 1)
+            for b, im, s in zip(back, imgs, streams):
+                assert (b == im).all(), (w, h)
+                assert (b == oracle.decompress(s)).all()
+        imgs = [synth.rgb8(96, 33, f) if f % 3 else rng.integers(0, 256, size=(33, 96, 3)).astype(np.uint8) for f in range(130)]
+        _, back = _decode_batch(enc, [oracle.compress(im) for im in imgs], (33, 96, 3), np.uint8)
+        assert all((b == im).all() for b, im in zip(back, imgs))
+        # corrupt streams
+        img = rng.integers(0, 256, size=(40, 50, 3), dtype=np.uint8)
+        good = oracle.compress(img)
+        gray = oracle.compress(img[:, :, 0].copy())
+        bad = [good[: len(good) // 2], good[:20], b"XLCS" + good[4:], good[:4] + b"\x07" + good[5:], good[:5] + b"\x09" + good[6:], gray,
+               good[:30] + b"\xff" * (len(good) - 30), good[:30] + bytes(len(good) - 30)]
+        for _ in range(40):
+            b = bytearray(good)
+            b[int(rng.integers(14, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            bad.append(bytes(b))
+        streams = [good] + bad + [good]
+        offs, blob = [], bytearray()
+        for s in streams:
+            offs.append(len(blob))
+            blob += s + bytes((-len(s)) % 16)
+        d_in = torch.from_numpy(np.frombuffer(bytes(blob) + bytes(16), dtype=np.uint8).copy()).cuda()
+        d_px = torch.zeros(img.size * len(streams), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        with pytest.raises(felics_amd.DecompressionError) as ei:
+            enc.decompress_batch_device(d_in.data_ptr(), offs, [len(s) for s in streams], d_px.data_ptr(), d_px.numel())
+        status = ei.value.status
+        assert status[0] == 0 and status[-1] == 0
+        host = d_px.cpu().numpy()
+        assert (host[: img.size].reshape(img.shape) == img).all() and (host[-img.size:].reshape(img.shape) == img).all()
+        assert status[1] == -1 and status[2] == -1          # truncated: IoError
+        assert status[3] == -7 and status[4] == -5 and status[5] == -6 and status[6] == -4
+        for i, s in enumerate(streams[1:-1], start=1):
+            try:
+                want = oracle.decompress(s)
+                host_ok = want.shape == img.shape
+            except Exception:
+                host_ok = False
+            if not host_ok:
+                assert status[i] != 0, i
+            elif status[i] == 0:
+                assert (host[i * img.size:(i + 1) * img.size].reshape(img.shape) == want).all(), i
+
+
 def test_three_hundred_mixed_streams(enc, oracle):
-    """Both forms of the device decoder (one wave per stream; 64 streams per wave, which the library picks from 1536 gray streams
-    up) on 300 streams of one shape and mixed content -- synthetic S1 / S2 / S3 frames, ramps with spikes, crops of the golden natural images -- encoded on the
+    """Both forms of the device decoder (one wave per stream; 64 streams per wave, which the library picks from 1536 gray / 2048 RGB
+    streams up) on 300 streams of one shape and mixed content -- synthetic S1 / S2 / S3 frames, ramps with spikes, crops of the golden natural images -- encoded on the
     GPU, decoded back on the GPU and compared with the frames; some of the streams also through the oracle's decoder."""
     import torch
     from felics_amd import synth
@@ -387,3 +457,20 @@ def test_three_hundred_mixed_streams(enc, oracle):
     host = d_out.cpu().numpy()
     for i in (0, 1, 63, 64, 255, 299):
         assert (oracle.decompress(host[int(offs[i]): int(offs[i] + lens[i])].tobytes()) == frames[i]).all(), i
+    # RGB8: 150 frames through both forms, then 2 100 streams (the 150, fourteen times over) through the library's own choice
+    wc, hc = 96, 40
+    rgb = [synth.rgb8(wc, hc, f) if f % 3 else rng.integers(0, 256, size=(hc, wc, 3)).astype(np.uint8) for f in range(150)]
+    d_rgb = torch.from_numpy(np.stack(rgb)).cuda()
+    capc = len(rgb) * (wc * hc * 3 * 2 + 64)
+    d_outc = torch.zeros(capc, dtype=torch.uint8, device="cuda")
+    offc, lenc = enc.compress_batch_device(d_rgb.data_ptr(), len(rgb), wc, hc, 1, 0, d_outc.data_ptr(), capc)
+    for form in ("0", "1"):
+        d_pxc = torch.zeros_like(d_rgb)
+        with _forced(form):
+            hdr, status = enc.decompress_batch_device(d_outc.data_ptr(), offc, lenc, d_pxc.data_ptr(), d_pxc.numel())
+        assert (status == 0).all() and (hdr.width, hdr.height, hdr.color_type) == (wc, hc, 1)
+        assert bool((d_pxc == d_rgb).all()), form
+    off14, len14 = np.tile(np.asarray(offc, dtype=np.uint64), 14), np.tile(np.asarray(lenc, dtype=np.uint64), 14)
+    d_px14 = torch.zeros((14,) + tuple(d_rgb.shape), dtype=torch.uint8, device="cuda")
+    hdr, status = enc.decompress_batch_device(d_outc.data_ptr(), off14, len14, d_px14.data_ptr(), d_px14.numel())
+    assert (status == 0).all() and all(bool((d_px14[r] == d_rgb).all()) for r in range(14))

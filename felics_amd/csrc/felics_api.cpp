@@ -94,10 +94,11 @@ struct felics_ctx {
     int device = -1;
     int next_lane = 0;          // lane of the next felics_submit_batch_device
     int nlanes = DEFAULT_LANES; // lanes in use (FELICS_LANES)
-    // Slices per sub-batch.  A blocking call has the GPU to itself: more slices let assign / pack follow the
-    // spine closely.  With two submissions in flight the other batch keeps the GPU busy, and every slice costs
-    // a launch and a hand-over per stage: few slices are faster there (measured: 12 -> 5.3, 6 -> 5.1, 3 -> 4.8 ms).
-    int slices_blocking = 6;    // FELICS_SLICES
+    // Slices per sub-batch: the stages follow each other slice by slice, so more slices let assign / pack start earlier behind the
+    // spine -- and every slice costs a launch, a hand-over per stage and a resume of every chain.  Round 5, blocking calls
+    // (profiles/r05/experiments.txt): 64 S1 frames 2 / 3 / 4 / 6 / 8 slices 2.95 / 2.68 / 2.75 / 2.79 / 2.76 ms, noise 4.19 / 4.37 /
+    // 4.52 / 4.96 / 5.37, one 4K frame 1.99 / 1.93 / 1.95 / 2.04 / 2.15 (round 4's pipeline wanted 6).
+    int slices_blocking = 3;    // FELICS_SLICES
     int slices_queued = 2;      // (round 5, tile-local pipeline: 1 slice 3.05, 2 2.54, 3 2.90, 4 2.86, 6 2.82 ms per step with two lanes; round 3 measured 2-4 lanes x 1-6 slices within 3 % of each other: profiles/r03/experiments.txt;
                                 // round 4, with k_scatter: 2 slices 2.94, 3 2.82-2.89, 4 2.78-2.80, 6 2.89-2.91, 8 2.96 ms; three lanes 3.06)
     // k_pack_g takes its tiles from the workgroup index while the lanes share the tail stream: one pack kernel then has the

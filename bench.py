@@ -457,6 +457,7 @@ def main():
             fr = torch.stack([st2.rgb8(WR, HR, f, device=dev) for f in range(FR)])
             capr = int(FR * WR * HR * 3 * 1.25) + (1 << 20)
             d_or = torch.empty(capr, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()  # (the frames are torch's work on torch's stream; the library runs on streams of its own)
             offr, lenr = enc.compress_batch_device(fr.data_ptr(), FR, WR, HR, 1, 0, d_or.data_ptr(), capr)
             o_r = np.array([offr[i % FR] for i in range(NR)], dtype=np.uint64)
             l_r = np.array([lenr[i % FR] for i in range(NR)], dtype=np.uint64)
@@ -467,7 +468,9 @@ def main():
             torch.cuda.synchronize()
             rgb_s = time.perf_counter() - t1
             if not (str_ == 0).all() or not bool((d_r[NR - 1] == fr[(NR - 1) % FR]).all()) or not bool((d_r[FR + 1] == fr[1]).all()):
-                raise SystemExit("GPU decoder (64 RGB streams per wave): pixels differ from the frames that were encoded")
+                raise SystemExit("GPU decoder (64 RGB streams per wave): pixels differ from the frames that were encoded (statuses nonzero: %d; frames "
+                                 "differing among the first 128: %s)" % (int((np.asarray(str_) != 0).sum()),
+                                                                          [i for i in range(128) if not bool((d_r[i] == fr[i % FR]).all())]))
             del d_r, d_or, fr
             big_rgb = {"streams": NR, "frame": "%dx%d RGB8" % (WR, HR), "gpu_MPix_s": round(NR * WR * HR / rgb_s / 1e6, 1),
                        "gpu_MSamples_s": round(3 * NR * WR * HR / rgb_s / 1e6, 1), "gpu_seconds_per_batch": round(rgb_s, 3),

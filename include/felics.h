@@ -95,7 +95,11 @@ int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, 
  *   d_out    : device buffer of d_out_cap bytes; stream i is written at
  *              offsets[i] (16-byte aligned, ascending) with lens[i] bytes
  *   offsets, lens : HOST arrays of n entries, filled on return
- * On FELICS_E_BUFFER_TOO_SMALL lens[0] holds the capacity needed. */
+ * On FELICS_E_BUFFER_TOO_SMALL lens[0] holds the capacity needed.
+ * The library works on HIP streams of its own (created non-blocking): the frames must be COMPLETE in memory when the
+ * call is made -- synchronise the stream that produced them first (hipStreamSynchronize / an event the host has
+ * waited for); the same holds for felics_submit_batch_device and for the streams handed to
+ * felics_decompress_batch_device.  What the library wrote is complete when the blocking call / felics_wait_batch returns. */
 int felics_compress_batch_device(felics_ctx *ctx, size_t n, const void *d_pixels, uint32_t w,
                                  uint32_t h, int color, int depth, void *d_out,
                                  size_t d_out_cap, uint64_t *offsets, uint64_t *lens);

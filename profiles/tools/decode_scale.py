@@ -29,6 +29,7 @@ else:
     frames = torch.stack([synth_torch.gray8(W, H, f, a.kind, device=dev) for f in range(F)])
 d_out = torch.empty(int(F * W * H * C * 1.25) + (1 << 20), dtype=torch.uint8, device=dev)
 enc = felics_amd.Encoder(0)
+torch.cuda.synchronize()  # (the frames are torch's work on torch's stream; the library runs on streams of its own)
 offs, lens = enc.compress_batch_device(frames.data_ptr(), F, W, H, 1 if a.rgb else 0, 0, d_out.data_ptr(), d_out.numel())
 host = d_out[: int(offs[-1] + lens[-1])].cpu().numpy()
 sample = [host[int(offs[i]): int(offs[i] + lens[i])].tobytes() for i in range(16)]

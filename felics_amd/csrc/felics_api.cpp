@@ -137,7 +137,7 @@ struct felics_ctx {
     int stage_launches[ST_COUNT] = {};
     DevBuf in, out;  // staging of the host-pointer entry point: the batch's frames, the chunks' output slots
     hipStream_t copy_in = nullptr, copy_out = nullptr;  // felics_compress_batch: frames to the device / streams back, beside the kernels
-    hipEvent_t h2d_done[MAX_LANES] = {};                // a chunk's frames have arrived (one per lane)
+    std::vector<hipEvent_t> h2d_done;                   // a chunk's frames have arrived (one per chunk of a host-buffer batch; grown on demand)
     hipEvent_t wait_before_submit = nullptr;            // the next sub-batch's first kernel waits for this event (set around one submit)
     DevBuf own;      // encode_device's own output when the caller gives none (the host entry point's fall-back for a chunk whose streams outgrew their slots)
     DevBuf dec_meta, dec_planes;  // GPU decoder: offsets | lens | status of a batch; Y / Co / Cg planes of RGB streams
@@ -1125,7 +1125,6 @@ int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, 
     if (!ctx->copy_in) {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking));
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking));
-        for (int i = 0; i < MAX_LANES; i++) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->h2d_done[i], hipEventDisableTiming));
     }
     const size_t per_pass = max_images_per_pass((uint64_t)w * h, planes, depth);
     // chunks: eight per batch (the first chunk's way in and the last one's way out are what the kernels cannot cover), none larger
@@ -1173,21 +1172,41 @@ int felics_compress_batch(felics_ctx *ctx, size_t n, const void *const *pixels, 
         (void)hipStreamSynchronize(ctx->copy_out);
         return r;
     };
-    for (size_t first = 0; first < n; first += chunk) {
-        const size_t cnt = std::min(chunk, n - first);
-        for (size_t i = 0; i < cnt && frame_bytes; i++) {  // the chunk's frames, on their way while the chunks before it are encoded
+    // All frames are put on their way at once, chunk by chunk with an event behind each chunk: the copy stream then runs back to
+    // back at the link's rate whatever the host is waiting for (with a chunk's copies queued only when its turn came, the stream
+    // stood idle while the host waited for an older chunk's kernels: 35 GB/s instead of the link's ~50).
+    // All frames are put on their way at once, chunk by chunk with an event behind each chunk: the copy stream then runs back to
+    // back at the link's rate whatever the host is waiting for (with a chunk's copies queued only when its turn came, the stream
+    // stood idle while the host waited for an older chunk's kernels: 35 GB/s instead of the link's ~50).
+    // (Eight chunks of a 64-frame batch: a chunk's kernels take ~2 ms whatever its size -- the chain of a single frame -- so with two
+    // chunks in flight sixteen chunks are 16 ms of kernels, four leave the first and the last chunk's 2.5 ms of copying uncovered;
+    // a short last chunk changed nothing: profiles/r05/experiments.txt.)
+    std::vector<size_t> starts;
+    for (size_t first = 0; first < n; first += chunk) starts.push_back(first);
+    const size_t nchunks = starts.size();
+    starts.push_back(n);
+    while (ctx->h2d_done.size() < nchunks) {
+        hipEvent_t ev = nullptr;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->h2d_done.push_back(ev);
+    }
+    for (size_t c = 0; c < nchunks; c++) {
+        const size_t first = starts[c], cnt = starts[c + 1] - first;
+        for (size_t i = 0; i < cnt && frame_bytes; i++) {
             const hipError_t e = hipMemcpyAsync((uint8_t *)ctx->in.p + (first + i) * frame_bytes, pixels[first + i], frame_bytes,
                                                 hipMemcpyHostToDevice, ctx->copy_in);
             if (e != hipSuccess) return drain(hip_fail(ctx, e, "copying frames to the device"));
         }
+        if (hipEventRecord(ctx->h2d_done[c], ctx->copy_in) != hipSuccess) return drain(hip_fail(ctx, hipGetLastError(), "hipEventRecord"));
+    }
+    for (size_t c = 0; c < nchunks; c++) {
+        const size_t first = starts[c], cnt = starts[c + 1] - first;
         if ((int)flying.size() == ctx->nlanes) {  // every lane is busy: the oldest chunk first (its lane is the next to be used)
             rc = land(flying.front());
             flying.erase(flying.begin());
             if (rc) return drain(rc);
         }
-        hipEvent_t ev = ctx->h2d_done[ctx->next_lane];
-        if (hipEventRecord(ev, ctx->copy_in) != hipSuccess) return drain(hip_fail(ctx, hipGetLastError(), "hipEventRecord"));
-        ctx->wait_before_submit = ev;  // the chunk's first kernel waits for its frames (launch_sub_batch)
+        ctx->wait_before_submit = ctx->h2d_done[c];  // the chunk's first kernel waits for its frames (launch_sub_batch)
         int ticket = -1;
         rc = felics_submit_batch_device(ctx, cnt, (const uint8_t *)ctx->in.p + first * frame_bytes, w, h, color, depth,
                                         (uint8_t *)ctx->out.p + first * slot, (size_t)(slot * cnt), &ticket);

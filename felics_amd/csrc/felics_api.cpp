@@ -415,7 +415,7 @@ int run_lane(felics_ctx *ctx, Lane &l, uint8_t *d_out, uint64_t slot_stride) {
             HIP_TRY(ctx, hipStreamWaitEvent(tl, l.assign_done[q], 0));
             if (bounds[q + 1] == bounds[q]) continue;
             StageTimer t(ctx, l, ST_PACK, tl, true);
-            launch_pack_t<T>(tl, d_planes, tloc.kq, tloc.pix, tloc.tile_slots, cap, (uint64_t *)l.status.p, (uint64_t *)l.tile_bitoff.p,
+            launch_pack_t<T>(tl, d_planes, tloc.kq, tloc.pix, tloc.ev, tloc.tile_slots, cap, (uint64_t *)l.status.p, (uint64_t *)l.tile_bitoff.p,
                              (uint32_t *)l.tile_bits.p, plane_carry, (uint32_t *)l.edge_first.p, (uint32_t *)l.edge_last.p, d_error, target, g,
                              bounds[q], bounds[q + 1], epoch, ctx->pack_tickets ? d_tickets + q : nullptr);
         }

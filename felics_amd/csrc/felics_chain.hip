@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void k_k_to_pixels_tl(const uint8_t *__restric
     uint8_t *dst = k_map + (uint64_t)plane * npix + (uint64_t)tile * SORT_TILE;
     for (uint32_t s = threadIdx.x; s < ns; s += 256) {
         const uint32_t p = pix[pt * cap + s];
-        if (p != 0xFFFFu) dst[p] = kq[pt * cap + s];
+        if (p != 0xFFFFu) dst[p & 0xFFFu] = kq[pt * cap + s];  // (bit 12: the above flag, for the single-pass pack)
     }
 }
 

@@ -96,7 +96,7 @@ constexpr uint32_t FRONT_TEST_VIOLATION = 1u, FRONT_SAFE_RANK = 2u;  // k_front'
 template <typename ET>
 struct TileLocal {
     ET *ev;                // [slot] value to Rice-code
-    uint16_t *pix;         // [slot] the event's pixel: offset in its tile; 0xFFFF in padding slots
+    uint16_t *pix;         // [slot] the event's pixel: offset in its tile (12 bits) | above << 12 (the sample lies above its neighbours); 0xFFFF in padding slots
     uint8_t *kq;           // [slot] k of the event (k_assign3)
     uint32_t *runtab;      // [(plane * nctx + c) * sort_tiles + tile] = first record of the tile's run of c (in the tile) | events << 16
     uint32_t *tile_slots;  // [plane * sort_tiles + tile] slots in use (a multiple of REC)
@@ -172,9 +172,9 @@ struct PackTarget {
     uint8_t *scratch;
     uint64_t plane_slot;
 };
-// the single-pass pack on the tile-local layout: k gathered from the tile's own slots (kq / pix / tile_slots of TileLocal)
+// the single-pass pack on the tile-local layout: the events' codes built from the tile's own slots (kq / pix / ev / tile_slots of TileLocal)
 template <typename T>
-void launch_pack_t(hipStream_t s, const T *planes, const uint8_t *kq, const uint16_t *pix, const uint32_t *tile_slots, uint32_t cap,
+void launch_pack_t(hipStream_t s, const T *planes, const uint8_t *kq, const uint16_t *pix, const void *ev, const uint32_t *tile_slots, uint32_t cap,
                    uint64_t *status, uint64_t *tile_bitoff, uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first,
                    uint32_t *edge_last, uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t st0, uint32_t st1, uint32_t epoch,
                    uint32_t *ticket);

@@ -21,6 +21,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "felics_device.h"
 #include "felics_kernels.h"
@@ -162,7 +163,8 @@ __device__ __forceinline__ uint32_t field_of(int v, int16_t) { return ((uint32_t
 //   mode & FRONT_SAFE_RANK: ranks from ballots instead of the returning add (a context's fallback once the order check has
 //   failed: no assumption about the LDS); mode & FRONT_TEST_VIOLATION: report a violation whatever the order (tests).
 //
-// Record in LDS: context << 22 | value << 13 | pixel offset in the tile (9 + 9 + 13 bits).
+// Record in LDS: context << 22 | value << 13 | above << 12 | pixel offset in the tile (9 + 9 + 1 + 12 bits; above = the sample lies
+// above its neighbours, the second flag bit of its code: compression.rs:139-144).  pix[slot] = the low 13 bits.
 // The chain of a context is the sequence of its runs over the tiles (felics_chain.hip).
 // (six workgroups per CU is what the LDS allows -- five for Y / Co / Cg planes -- and the registers are held to that)
 // ------------------------------------------------------------------------------------------
@@ -174,8 +176,8 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 5))) __global__ __launch
     constexpr uint32_t NC = nctx_of<T>();
     constexpr uint32_t QUARTER = SORT_TILE / 4, TRIPS = QUARTER / 256;
     constexpr uint32_t PER = NC / 256;  // contexts per thread in step 3
-    constexpr uint32_t KEY = 0xFFC01FFFu;  // context and pixel offset of a record
-    static_assert(SORT_TILE % 1024 == 0 && SORT_TILE <= (1u << 13), "four whole trips per wave; 13 bits of pixel offset");
+    constexpr uint32_t KEY = 0xFFC00FFFu;  // context and pixel offset of a record
+    static_assert(SORT_TILE % 1024 == 0 && SORT_TILE <= (1u << 12), "four whole trips per wave; 12 bits of pixel offset");
     static_assert(NC % 256 == 0 && NC <= 512, "a thread takes NC / 256 contexts; 9 bits of context");
     __shared__ uint32_t srt[SORT_TILE + 1 + 256];  // the tile's events, contexts ascending, raster order inside, a sentinel behind the last; [.. + 1 + thread]: where slots without an event are "placed"
     __shared__ uint32_t cnt[4][NC + 64];      // per wave and context: count, then cursor into srt; [NC + lane]: what slots without an event count on
@@ -266,7 +268,7 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 5))) __global__ __launch
                 const int not_above = o >> 31;
                 const uint32_t val = bitop3<BT_SEL>((uint32_t)(dd ^ below), (uint32_t)o, (uint32_t)not_above);  // L - p - 1 | p - L | p - H - 1
                 const uint32_t in_range = bitop3<BT_ANDN>((uint32_t)not_above, (uint32_t)below, 0u);               // all ones: no event
-                const uint32_t off = row0 - begin + 64 * j + lane;
+                const uint32_t off = (row0 - begin + 64 * j + lane) | bitop3<BT_ANDN>(0x1000u, (uint32_t)not_above, 0u);  // | above << 12
                 rec[d * 4 + j] = ((ctx << 22) | (val << 13) | off) | in_range;
                 // rank: the counter of the event's context, or this lane's own
                 const uint32_t at = cnt_at + bitop3<BT_SEL>(dummy_at, ctx << 2, in_range);
@@ -282,7 +284,7 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 5))) __global__ __launch
                 uint32_t r = 0xFFFFFFFFu;
                 if (i < end && i >= 2) {
                     const PixelClass pc = classify(pl, i, xy.x, xy.y, W);
-                    if (pc.cls != CLS_IN) r = (pc.ctx << 22) | (pc.val << 13) | (i - begin);
+                    if (pc.cls != CLS_IN) r = (pc.ctx << 22) | (pc.val << 13) | (pc.cls == CLS_ABOVE ? 0x1000u : 0u) | (i - begin);
                 }
                 xy.advance(64, W);
                 rec[d * 4 + j] = r;
@@ -925,6 +927,57 @@ __device__ __forceinline__ GroupGeom group_geometry(const T *__restrict__ pl, ui
     return gg;
 }
 
+// The code of a pixel IN RANGE, left-aligned in 32 bits, and its length (compression.rs:129-133): p against its two neighbours a, b
+// (unordered; all three in field_at's form): `1`, then p - L phased-in on n = H - L + 1 values (phase_in_coding.rs:59-84):
+// r = (p - L + P) mod n, P = 2^m = the largest power of two <= n; r < 2 P - n: r in m bits, else r + 2 P - n in m + 1 bits.
+// Built for every pixel (garbage, and harmless, where the pixel is an event: the caller keeps the event's word instead).
+// K31 = 0x80000000 in a vector register (vgpr_const).
+struct PixelCode {
+    uint32_t c32, len;
+};
+__device__ __forceinline__ PixelCode code_in_range(uint32_t p, uint32_t a, uint32_t b, uint32_t K31) {
+    const uint32_t L = min_u16(a, b), H = max_u16(a, b);
+    const uint32_t ctx = H - L;
+    const uint32_t d = p - L;  // in range: 0 <= d <= ctx
+    const uint32_t n = ctx + 1u;
+    const uint32_t z = (uint32_t)__builtin_clz(n);  // n >= 1
+    const uint32_t P = K31 >> z;
+    const uint32_t r0 = d + P, r1 = r0 - n;
+    const uint32_t r = bitop3<BT_SEL>(r0, r1, (uint32_t)((int)r1 >> 31));  // r0 mod n
+    const uint32_t P2 = twice(P), right_p = P2 - n;
+    const int is_short = (int)(r - right_p) >> 31;
+    const uint32_t code_in = r + bitop3<BT_SEL>(P, P2 + right_p, (uint32_t)is_short);  // `1` in front of m or m + 1 bits
+    PixelCode pc;
+    pc.len = (33u - z) + (uint32_t)is_short;                                            // m + 1 or m + 2
+    pc.c32 = code_in << ((32u - pc.len) & 31u);
+    return pc;
+}
+
+// The WORD of an event (k_pack_t builds it where it gathers the tile's events, once per event instead of once per pixel): its code
+// `00` / `01` (below / above), then the value Rice-coded -- q ones, `0`, k low bits (rice_coding.rs:26-38) -- left-aligned, with k
+// and the length beside it:   code << (32 - len) | k << 6 | len   for len = q + k + 3 <= RICE_WORD_MAX_LEN (the code's bits end above
+// bit 9), else   len << 9 | k << 6 | 63: such a group of pixels is coded the general way (it needs k and the exact length).
+// A pixel that is no event has the word 0.   K7F = 0x7FFFFFFF in a vector register.
+constexpr uint32_t RICE_WORD_MAX_LEN = 23, RICE_WORD_LONG = 63;
+constexpr uint32_t WORD_PATH_MAX_SLOTS = 2048;  // k_pack_t builds the events' codes per event up to this many slots in use of a tile (of 4096 pixels), per pixel beyond
+__device__ __forceinline__ uint32_t rice_word(uint32_t val, uint32_t k, uint32_t above /* 0 or 1 */, uint32_t K7F) {
+    const uint32_t q = val >> k;
+    const uint32_t len = q + k + 3u;
+    const uint32_t ones = K7F >> ((31u - q) & 31u);               // q ones (q <= 20 wherever the code is used)
+    const uint32_t head = bitop3<BT_OR_ANDN>(ones, ones + 1u, above - 1u);   // `0` / `1` (above) in front of them
+    const uint32_t rice = bitop3<BT_OR_ANDN>(head << (k + 1u), val, ~0u << k);  // then `0` and the k low bits of val
+    const uint32_t c32 = rice << ((32u - len) & 31u);
+    return len <= RICE_WORD_MAX_LEN ? (c32 | (k << 6) | len) : ((len << 9) | (k << 6) | RICE_WORD_LONG);
+}
+__device__ __forceinline__ uint32_t word_k(uint32_t w) { return (w >> 6) & 7u; }
+// Where the word of pixel j of the tile lies in LDS: [quad of the thread's sixteen pixels][thread][pixel of the quad] -- a thread's 16-byte
+// read of a quad is then 16 bytes from its neighbour's (pixel-major, a wave's reads were 64 bytes apart: sixteen lanes on the same banks,
+// and a tile without a single event took twice as long as before).  PACK_TILE and beyond (the dump word): as they are.
+__device__ __forceinline__ uint32_t word_index(uint32_t j) {
+    return j >= PACK_TILE ? j : (((j >> 2) & 3u) << 10) | ((j >> 4) << 2) | (j & 3u);
+}
+static_assert(PACK_TILE == 4096 && PACK_PER_THREAD == 16, "word_index: 256 threads x 4 quads x 4 pixels");
+
 // One pixel's code, left-aligned in 32 bits, and its length (compression.rs:124-145): p against its two neighbours a, b
 // (unordered; all three in field_at's form), k = the Rice parameter of the pixel's context (used if p is out of range).
 //   in range (L <= p <= H): `1`, then p - L phased-in on n = H - L + 1 values (phase_in_coding.rs:59-84): r = (p - L + P) mod n,
@@ -932,9 +985,6 @@ __device__ __forceinline__ GroupGeom group_geometry(const T *__restrict__ pl, ui
 //   below / above: `00` / `01`, then L - p - 1 / p - H - 1 Rice-coded: q ones, `0`, k low bits (rice_coding.rs:26-38).
 // Both are built and one is kept.  A Rice code longer than 32 bits comes out as garbage with len > 32: the caller redoes
 // such a group the general way.  K31 = 0x80000000, K7F = 0x7FFFFFFF in vector registers (vgpr_const).
-struct PixelCode {
-    uint32_t c32, len;
-};
 __device__ __forceinline__ PixelCode code_pixel(uint32_t p, uint32_t a, uint32_t b, uint32_t k, uint32_t K31, uint32_t K7F) {
     const uint32_t L = min_u16(a, b), H = max_u16(a, b);
     const uint32_t ctx = H - L;
@@ -985,6 +1035,67 @@ __device__ __forceinline__ void load_group(const T *__restrict__ pl, uint32_t fi
 
 // The codes of a thread's 16 pixels WITHOUT a branch (the common case): every pixel below the first image row, the group
 // inside the plane.  Same codes as classify + put_pixel, which stay as the general path (first row, the plane's first
+// two samples and its ragged end, Rice codes too long for a word, images narrower than 16 pixels).
+//   * an EVENT's code comes ready-made from its word (words[pixel]: rice_word, built by the gather); a pixel in range (word 0)
+//     takes the phased-in code of p - L, built here for all sixteen pixels and kept where the word is 0;
+//   * neighbours: left and above (misc.rs:6-24, interior case); the left neighbour of pixel j is pixel j - 1 of the group.
+//   * a first-column pixel (j0) takes above and two rows up (above-right in row 1) instead; the pair is unordered (H = max,
+//     L = min), so that rule only replaces the LEFT sample of that one pixel by `special`, which the caller fetched.  One
+//     thread in 240 has such a pixel: its code is built a second time where a wave holds such a thread.
+// Returns the total length in bits (exact also when a Rice code did not fit its word: the word then carries the length);
+// longest = the longest code's length field (RICE_WORD_LONG: one did not fit).
+template <typename T>
+__device__ __forceinline__ uint32_t group_codes_w(const GroupSamples<T> &g, const uint32_t *words, const T *__restrict__ pl, uint32_t first,
+                                                uint32_t W, uint32_t j0, int special, uint32_t (&c32)[PACK_PER_THREAD],
+                                                uint32_t (&len)[PACK_PER_THREAD], uint32_t &longest) {
+    const uint32_t off = threadIdx.x * PACK_PER_THREAD;
+    const uint32_t K31 = vgpr_const(0x80000000u);
+    uint32_t left = field_of(g.before, T());  // the sample in front of the group
+    longest = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < PACK_PER_THREAD / 4; u++) {  // (four words at a time: sixteen of them at once cost twelve more registers)
+        const uint4 c = *reinterpret_cast<const uint4 *>(words + u * (PACK_TILE / 4) + threadIdx.x * 4);  // word_index(off + 4 u ..)
+        const uint32_t wq[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint32_t j = 4 * u + i;
+            const uint32_t p = field_at(g.cw, j, T());
+            const PixelCode pc = code_in_range(p, left, field_at(g.uw, j, T()), K31);
+            const uint32_t lf = wq[i] & 63u;
+            const uint32_t in_range = (uint32_t)((int)(lf - 1u) >> 31);  // all ones: the word is 0, no event
+            c32[j] = bitop3<BT_SEL>(pc.c32, wq[i] & ~0x1FFu, in_range);
+            len[j] = bitop3<BT_SEL>(pc.len, lf, in_range);
+            longest = max_u16(longest, len[j]);
+            left = p;
+        }
+    }
+    if (__ballot(j0 < PACK_PER_THREAD) != 0) {  // (wave-uniform: a quarter of the waves of a 4K plane)
+        if (j0 < PACK_PER_THREAD && (words[word_index(off + j0)] & 63u) == 0u) {  // (an event's word does not depend on who its neighbours are here)
+            const uint32_t i0 = first + j0;
+            const PixelCode pc = code_in_range(field_of((int)pl[i0], T()), field_of(special, T()), field_of((int)pl[i0 - W], T()), K31);
+#pragma unroll
+            for (uint32_t j = 0; j < PACK_PER_THREAD; j++) {
+                c32[j] = j == j0 ? pc.c32 : c32[j];
+                len[j] = j == j0 ? pc.len : len[j];
+            }
+            longest = max_u16(longest, pc.len);
+        }
+    }
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < PACK_PER_THREAD; j++) total += len[j];
+    if (longest == RICE_WORD_LONG) {  // (rare: full-scale spikes) a word that carries its code's length instead of the code
+        for (uint32_t j = 0; j < PACK_PER_THREAD; j++) {
+            const uint32_t w = words[word_index(off + j)];
+            if ((w & 63u) == RICE_WORD_LONG) total += (w >> 9) - RICE_WORD_LONG;
+        }
+    }
+    return total;
+}
+
+// group_codes for a tile where most pixels are events (k_pack_t: the tile's slots outnumber WORD_PATH_MAX_SLOTS): k per pixel in LDS,
+// both codes built for every pixel and one kept.  Every pixel below the first image row, the group
+// inside the plane.  Same codes as classify + put_pixel, which stay as the general path (first row, the plane's first
 // two samples and its ragged end, codes longer than 32 bits, images narrower than 16 pixels).
 //   * neighbours: left and above (misc.rs:6-24, interior case); the left neighbour of pixel j is pixel j - 1 of the group.
 //   * a first-column pixel (j0) takes above and two rows up (above-right in row 1) instead; the pair is unordered (H = max,
@@ -993,7 +1104,7 @@ __device__ __forceinline__ void load_group(const T *__restrict__ pl, uint32_t fi
 // kq = the tile's k bytes in LDS.  Returns the total length in bits (exact also when a code is longer than 32 bits: only
 // that code's c32 is garbage then); longest = the longest code's length.
 template <typename T>
-__device__ __forceinline__ uint32_t group_codes(const GroupSamples<T> &g, const uint8_t *kq, const T *__restrict__ pl, uint32_t first,
+__device__ __forceinline__ uint32_t group_codes_k(const GroupSamples<T> &g, const uint8_t *kq, const T *__restrict__ pl, uint32_t first,
                                                 uint32_t W, uint32_t j0, int special, uint32_t (&c32)[PACK_PER_THREAD],
                                                 uint32_t (&len)[PACK_PER_THREAD], uint32_t &longest) {
     const uint32_t off = threadIdx.x * PACK_PER_THREAD;
@@ -1038,36 +1149,38 @@ __device__ __forceinline__ uint32_t group_codes(const GroupSamples<T> &g, const 
 // lengths / codes (code_length / put_pixel) -- pixel by pixel from global memory, once to count the bits and later once more
 // to build the codes straight into the tile's bit window.  Functions of their own, not inlined: inside the kernel their
 // address arithmetic was hoisted in front of the branch and their registers pushed the common path's sixteen codes into
-// scratch memory.  (kq arrives as a generic pointer into LDS; these paths are rare.)
+// scratch memory.  (words arrives as a generic pointer into LDS: k of an event is in its word; these paths are rare.)
 struct GeneralGroup {
     uint32_t tile_first, first, end, W, H, npix, color, depth, has_header;
+    uint32_t by_word;  // k of pixel i: word_k(words[i]) (k_pack_t's word path), or byte i of the same LDS array (its k path)
 };
 template <typename T, typename FR, typename F>
-__device__ __forceinline__ void walk_group_global(const T *__restrict__ pl, const uint8_t *kq, const GeneralGroup &g, FR &&raw, F &&f) {
+__device__ __forceinline__ void walk_group_global(const T *__restrict__ pl, const uint32_t *words, const GeneralGroup &g, FR &&raw, F &&f) {
     Coord xy;
     xy.set(g.first, g.W);
     for (uint32_t i = g.first; i < min(g.end, g.first + PACK_PER_THREAD); i++) {
         if (i < 2)
             raw(i, (uint32_t)(int)pl[i]);  // stored as 32-bit values (compression.rs:105-106)
         else
-            f(classify(pl, i, xy.x, xy.y, g.W), (uint32_t)kq[i - g.tile_first]);
+            f(classify(pl, i, xy.x, xy.y, g.W),
+              g.by_word ? word_k(words[word_index(i - g.tile_first)]) : (uint32_t)reinterpret_cast<const uint8_t *>(words)[i - g.tile_first]);
         xy.advance(1, g.W);
     }
 }
 template <typename T>
-__device__ __noinline__ uint32_t general_group_bits(const uint8_t *kq, const T *pl, const GeneralGroup g) {
+__device__ __noinline__ uint32_t general_group_bits(const uint32_t *words, const T *pl, const GeneralGroup g) {
     uint32_t bits = 0;
     if (g.first < g.end) {
         const uint32_t npix = g.npix;
         if (g.has_header) bits += 8u * 14u;
-        walk_group_global(pl, kq, g, [&](uint32_t, uint32_t) { bits += npix == 1 ? 64u : 32u; },
+        walk_group_global(pl, words, g, [&](uint32_t, uint32_t) { bits += npix == 1 ? 64u : 32u; },
                           [&](const PixelClass &pc, uint32_t k) { bits += code_length(pc, k); });
     }
     return bits;
 }
 // (the window's word 0 is stream word win_word0; bit 0 of this group is stream bit my_lo)
 template <typename T>
-__device__ __noinline__ void general_group_place(const uint8_t *kq, const T *pl, const GeneralGroup g, uint32_t *win,
+__device__ __noinline__ void general_group_place(const uint32_t *words, const T *pl, const GeneralGroup g, uint32_t *win,
                                                  uint32_t win_words, uint64_t win_word0, uint64_t my_lo) {
     LaneBits bw;
     bw.win = win;
@@ -1081,7 +1194,7 @@ __device__ __noinline__ void general_group_place(const uint8_t *kq, const T *pl,
         bw.put(g.H, 32);
     }
     const uint32_t npix = g.npix;
-    walk_group_global(pl, kq, g,
+    walk_group_global(pl, words, g,
                       [&](uint32_t, uint32_t rv) {
                           bw.put(rv, 32);  // write_signed(32, p): sign-extended sample
                           if (npix == 1) bw.put(0u, 32);
@@ -1168,9 +1281,10 @@ __device__ __forceinline__ void look_back(const FusedArgs &fa, FusedLDS &fl, uin
 }
 
 // The single-pass pack of ONE tile by a workgroup (the body of k_pack_t): see the comment above.
-// gsm = this thread's samples (valid where gg.fast); kq = the tile's k bytes in LDS and fl.win all zero, with a barrier behind both.
-template <typename T>
-__device__ __forceinline__ void pack_tile_fused(const GroupSamples<T> &gsm, const uint8_t *kq, FusedLDS &fl, const T *__restrict__ planes,
+// gsm = this thread's samples (valid where gg.fast); words = the tile's event words in LDS (BY_WORD: 0 where a pixel is no event; else
+// the array holds k of pixel j in byte j) and fl.win all zero, with a barrier behind both.
+template <typename T, bool BY_WORD>
+__device__ __forceinline__ void pack_tile_fused(const GroupSamples<T> &gsm, const uint32_t *words, FusedLDS &fl, const T *__restrict__ planes,
                                                 const FusedArgs &fa, uint32_t tile, uint32_t plane, const GroupGeom &gg) {
     uint32_t (&win)[FUSED_WIN_WORDS + 2] = fl.win;
     uint32_t (&wsum)[PACK_THREADS / 64] = fl.wsum;
@@ -1190,15 +1304,20 @@ __device__ __forceinline__ void pack_tile_fused(const GroupSamples<T> &gsm, cons
     // first-column pixel in it (whose second neighbour -- two rows up, or above-right in row 1 -- comes from global memory).
     // (The general path is two function calls, placed where none of the common path's codes is in a register: the count in
     // front of group_codes, the placement behind the common path's.)
-    const GeneralGroup general{tile_first, first, end, W, H, npix, fa.color, fa.depth, has_header ? 1u : 0u};
+    const GeneralGroup general{tile_first, first, end, W, H, npix, fa.color, fa.depth, has_header ? 1u : 0u, BY_WORD ? 1u : 0u};
     uint32_t bits = 0;
-    if (!gg.fast) bits = general_group_bits<T>(kq, pl, general);  // count now, build the codes straight into the window later
+    if (!gg.fast) bits = general_group_bits<T>(words, pl, general);  // count now, build the codes straight into the window later
     uint32_t c32[PACK_PER_THREAD], len[PACK_PER_THREAD];
     bool in_registers = false;
     if (gg.fast) {
         uint32_t longest;
-        bits = group_codes<T>(gsm, kq, pl, first, W, gg.j0, gg.special, c32, len, longest);
-        in_registers = longest <= 32u;  // (a longer code: the lengths stand, the codes are built again the general way)
+        if (BY_WORD) {
+            bits = group_codes_w<T>(gsm, words, pl, first, W, gg.j0, gg.special, c32, len, longest);
+            in_registers = longest != RICE_WORD_LONG;  // (a Rice code too long for its word: the lengths stand, the codes are built again the general way)
+        } else {
+            bits = group_codes_k<T>(gsm, reinterpret_cast<const uint8_t *>(words), pl, first, W, gg.j0, gg.special, c32, len, longest);
+            in_registers = longest <= 32u;  // (a longer code: the lengths stand, the codes are built again the general way)
+        }
     }
     const uint32_t inc = wave_incl_scan(bits);
     if (lane == 63) wsum[wave] = inc;
@@ -1259,7 +1378,7 @@ __device__ __forceinline__ void pack_tile_fused(const GroupSamples<T> &gsm, cons
                 at += len[j];
             }
         }
-        if (!in_registers && bits != 0) general_group_place<T>(kq, pl, general, win, FUSED_WIN_WORDS, 0, my_rel);
+        if (!in_registers && bits != 0) general_group_place<T>(words, pl, general, win, FUSED_WIN_WORDS, 0, my_rel);
         PSTAMP(8);
         if (wave == 0) look_back(fa, fl, tile, plane, tile_total);
         __syncthreads();
@@ -1285,7 +1404,7 @@ __device__ __forceinline__ void pack_tile_fused(const GroupSamples<T> &gsm, cons
                 __syncthreads();
             }
             if (bits != 0 && my_last >= wb && my_first < wb + FUSED_WIN_WORDS)
-                general_group_place<T>(kq, pl, general, win, FUSED_WIN_WORDS, first_word + wb, my_lo);
+                general_group_place<T>(words, pl, general, win, FUSED_WIN_WORDS, first_word + wb, my_lo);
             __syncthreads();
             flush_window(wb, 0u, tile_lo);
         }
@@ -1311,24 +1430,29 @@ extern "C" __attribute__((visibility("default"))) int felics_debug_pack_stamps(u
 #endif
 
 // ------------------------------------------------------------------------------------------
-// k_pack_t (round 5): the single-pass pack on the tile-local layout.  The tile's k bytes lie where the front kernel put the
-// tile's events -- kq[slot], pix[slot] = the event's pixel, slots [0, tile_slots) of the tile -- so the gather is one
-// contiguous read: four slots per thread and round, k dropped into the LDS array the pack stage indexes by pixel (padding
-// slots, pix = 0xFFFF, into a dump byte behind it).  No run table, no chains in this kernel.
+// k_pack_t (round 5): the single-pass pack on the tile-local layout.  A tile's events lie where the front kernel put them --
+// ev[slot] the value, pix[slot] the pixel's offset and the above flag, kq[slot] the k that k_assign3 left, slots [0, tile_slots) of
+// the tile -- so the gather is one contiguous read: four slots per thread and round, and each event's CODE is built right there,
+// once per event (rice_word), and dropped into the LDS array the code phase indexes by pixel (padding slots, pix = 0xFFFF, into
+// a dump word behind it).  The code phase then builds the phased-in code of every pixel and keeps the event's word where there is
+// one: the Rice code is no longer built for every pixel (of which one in seven is an event).  No run table, no chains here.
 // ------------------------------------------------------------------------------------------
 struct TSources {
     const uint8_t *kq;
     const uint16_t *pix;
+    const void *ev;  // u8 (gray planes) / u16 (Y / Co / Cg planes) per slot
     const uint32_t *tile_slots;
     uint32_t cap, sort_ntiles;
 };
 
 template <typename T>
-__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 6))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_t(const T *__restrict__ planes, TSources ts, FusedArgs fa,
+__attribute__((amdgpu_waves_per_eu(6))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_t(const T *__restrict__ planes, TSources ts, FusedArgs fa,
                                                                                                uint32_t sort_tile_begin, uint32_t pack_tile_end) {
-    __shared__ alignas(16) uint8_t kq[PACK_TILE + 16];  // k of pixel tile_first + j (event pixels only: the others hold what was there); [PACK_TILE]: dump
+    using ET = typename std::conditional<sizeof(T) == 1, uint8_t, uint16_t>::type;
+    __shared__ alignas(16) uint32_t words[PACK_TILE + 4];  // the word of the event at pixel tile_first + j, 0 where there is none; [PACK_TILE]: dump
     __shared__ FusedLDS fl;
     static_assert(SORT_TILE == PACK_TILE, "one workgroup = one sort tile = one pack tile (one look-back per workgroup)");
+    static_assert(PACK_TILE == 4 * 4 * PACK_THREADS, "the clearing of words: four 16-byte stores per thread");
     uint32_t x, plane;
 #ifdef FELICS_PACK_STAMPS
     if (threadIdx.x == 0) {
@@ -1347,33 +1471,77 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 7 : 6))) __global__ __launch
     GroupSamples<T> gsm;
     if (gg.fast) load_group(pl, st * PACK_TILE + threadIdx.x * PACK_PER_THREAD, fa.W, gsm);
     for (uint32_t j = threadIdx.x; j < FUSED_WIN_WORDS + 2; j += PACK_THREADS) fl.win[j] = 0;  // the bit window (barrier: behind the gather)
-    PSTAMP(9);
-    // ---- round trip 2: k and pixel offsets of the tile's slots.  (A thread past the end takes the last four slots again -- the
-    // same k goes to the same pixels twice -- so the loads of a round run under no lane-wise condition.)
-    constexpr uint32_t GR = 3;  // rounds in flight together: 3072 slots (a 4K frame's tile has ~2400 in use)
     const uint8_t *ksrc = ts.kq + pt * ts.cap;
     const uint16_t *psrc = ts.pix + pt * ts.cap;
-    for (uint32_t s0 = 0; s0 < ns; s0 += GR * 4 * PACK_THREADS) {
-        uint32_t kv[GR];
-        uint2 pv[GR];
+    constexpr uint32_t GR = 3;  // rounds in flight together: 3072 slots
+    if (ns <= WORD_PATH_MAX_SLOTS) {
+        // ---- round trip 2, few events (smooth and natural content: a 4K S1 tile has ~600 slots in use): every event's code built
+        // here, once per event.  Only the waves whose slots exist do that (wave w of round u: slots u * 1024 + w * 256 ..).
 #pragma unroll
-        for (uint32_t u = 0; u < GR; u++) {
-            const uint32_t s = min(s0 + u * 4 * PACK_THREADS + threadIdx.x * 4, ns - 4u);
+        for (uint32_t u = 0; u < 4; u++) reinterpret_cast<uint4 *>(words)[threadIdx.x + u * PACK_THREADS] = make_uint4(0u, 0u, 0u, 0u);
+        PSTAMP(9);
+        const ET *esrc = reinterpret_cast<const ET *>(ts.ev) + pt * ts.cap;
+        const uint32_t K7F = vgpr_const(0x7FFFFFFFu);
+        constexpr uint32_t WR = (WORD_PATH_MAX_SLOTS + 4 * PACK_THREADS - 1) / (4 * PACK_THREADS);  // rounds at most
+        const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u)) * 4u;
+        uint32_t kv[WR];
+        uint2 pv[WR];
+        uint32_t evv[WR][sizeof(ET) == 1 ? 1 : 2];
+#pragma unroll
+        for (uint32_t u = 0; u < WR; u++) {  // (a thread past the end takes the tile's last four slots: no lane-wise condition on a load)
+            const uint32_t s = min(u * 4 * PACK_THREADS + threadIdx.x * 4, max(ns, 4u) - 4u);
             kv[u] = *reinterpret_cast<const uint32_t *>(ksrc + s);
             pv[u] = *reinterpret_cast<const uint2 *>(psrc + s);
+            __builtin_memcpy(evv[u], esrc + s, 4 * sizeof(ET));
         }
+        __syncthreads();  // the words are cleared before the first of them is written
 #pragma unroll
-        for (uint32_t u = 0; u < GR; u++) {
-            kq[min(pv[u].x & 0xFFFFu, PACK_TILE)] = (uint8_t)kv[u];
-            kq[min(pv[u].x >> 16, PACK_TILE)] = (uint8_t)(kv[u] >> 8);
-            kq[min(pv[u].y & 0xFFFFu, PACK_TILE)] = (uint8_t)(kv[u] >> 16);
-            kq[min(pv[u].y >> 16, PACK_TILE)] = (uint8_t)(kv[u] >> 24);
+        for (uint32_t u = 0; u < WR; u++) {
+            if (u * 4 * PACK_THREADS + wave_first < ns) {  // (wave-uniform)
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) {
+                    const uint32_t pw = (i & 2u) ? pv[u].y : pv[u].x;
+                    const uint32_t p = (i & 1u) ? pw >> 16 : pw & 0xFFFFu;
+                    const uint32_t k = (kv[u] >> (8u * i)) & 7u;
+                    const uint32_t e = sizeof(ET) == 1 ? (evv[u][0] >> (8u * i)) & 0xFFu
+                                                       : (evv[u][sizeof(ET) == 1 ? 0 : (i >> 1)] >> (16u * (i & 1u))) & 0xFFFFu;
+                    // (a padding slot, pix = 0xFFFF: whatever its k and value make goes to the dump word)
+                    words[word_index(min(p & 0xEFFFu, PACK_TILE))] = rice_word(e, k, (p >> 12) & 1u, K7F);
+                }
+            }
         }
+        PSTAMP(2);
+        __syncthreads();
+        PSTAMP(3);
+        if (st < pack_tile_end) pack_tile_fused<T, true>(gsm, words, fl, planes, fa, st, plane, gg);
+    } else {
+        // ---- round trip 2, many events (noise, texture): k of every event into byte `pixel` of the array; both codes of every pixel
+        // are then built in the code phase (there are more slots than pixels to build a code for).  (A thread past the end takes
+        // the last four slots again -- the same k goes to the same pixels twice -- so the loads run under no lane-wise condition.)
+        uint8_t *kq = reinterpret_cast<uint8_t *>(words);
+        PSTAMP(9);
+        for (uint32_t s0 = 0; s0 < ns; s0 += GR * 4 * PACK_THREADS) {
+            uint32_t kv[GR];
+            uint2 pv[GR];
+#pragma unroll
+            for (uint32_t u = 0; u < GR; u++) {
+                const uint32_t s = min(s0 + u * 4 * PACK_THREADS + threadIdx.x * 4, ns - 4u);
+                kv[u] = *reinterpret_cast<const uint32_t *>(ksrc + s);
+                pv[u] = *reinterpret_cast<const uint2 *>(psrc + s);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < GR; u++) {  // (pix: offset | above << 12; padding 0xFFFF -> the dump byte)
+                kq[min(pv[u].x & 0xEFFFu, PACK_TILE)] = (uint8_t)kv[u];
+                kq[min((pv[u].x >> 16) & 0xEFFFu, PACK_TILE)] = (uint8_t)(kv[u] >> 8);
+                kq[min(pv[u].y & 0xEFFFu, PACK_TILE)] = (uint8_t)(kv[u] >> 16);
+                kq[min((pv[u].y >> 16) & 0xEFFFu, PACK_TILE)] = (uint8_t)(kv[u] >> 24);
+            }
+        }
+        PSTAMP(2);
+        __syncthreads();
+        PSTAMP(3);
+        if (st < pack_tile_end) pack_tile_fused<T, false>(gsm, words, fl, planes, fa, st, plane, gg);
     }
-    PSTAMP(2);
-    __syncthreads();
-    PSTAMP(3);
-    if (st < pack_tile_end) pack_tile_fused<T>(gsm, kq, fl, planes, fa, st, plane, gg);
 }
 
 // Words shared by two tiles (and the last, partly filled word of a plane): OR of the two halves.
@@ -1518,7 +1686,7 @@ template void launch_pack<int32_t>(hipStream_t, const int32_t *, const uint8_t *
                                    const Geometry &, uint32_t, uint32_t);
 
 template <typename T>
-void launch_pack_t(hipStream_t s, const T *planes, const uint8_t *kq, const uint16_t *pix, const uint32_t *tile_slots, uint32_t cap,
+void launch_pack_t(hipStream_t s, const T *planes, const uint8_t *kq, const uint16_t *pix, const void *ev, const uint32_t *tile_slots, uint32_t cap,
                    uint64_t *status, uint64_t *tile_bitoff, uint32_t *tile_bits, uint64_t *plane_carry, uint32_t *edge_first,
                    uint32_t *edge_last, uint32_t *error, const PackTarget &to, const Geometry &g, uint32_t st0, uint32_t st1, uint32_t epoch,
                    uint32_t *ticket) {
@@ -1526,14 +1694,14 @@ void launch_pack_t(hipStream_t s, const T *planes, const uint8_t *kq, const uint
     const FusedArgs fa{status, tile_bitoff, tile_bits, plane_carry, edge_first, edge_last, error,
                        PlaneOut{to.out, to.slot_stride, to.scratch, to.plane_slot, g.planes_per_image},
                        g.W, g.H, g.npix, g.pack_tiles, g.color, g.depth, epoch, ticket, g.nplanes};
-    const TSources ts{kq, pix, tile_slots, cap, g.sort_tiles};
+    const TSources ts{kq, pix, ev, tile_slots, cap, g.sort_tiles};
     // (the kernel takes its tile from the ticket, or from blockIdx.x of this one-dimensional grid: never from blockIdx.y)
     FELICS_LAUNCH((k_pack_t<T>), dim3((st1 - st0) * g.nplanes), dim3(PACK_THREADS), s, planes, ts, fa, st0, g.pack_tiles);
 }
-template void launch_pack_t<uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, const uint16_t *, const uint32_t *, uint32_t, uint64_t *,
+template void launch_pack_t<uint8_t>(hipStream_t, const uint8_t *, const uint8_t *, const uint16_t *, const void *, const uint32_t *, uint32_t, uint64_t *,
                                      uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, const PackTarget &,
                                      const Geometry &, uint32_t, uint32_t, uint32_t, uint32_t *);
-template void launch_pack_t<int16_t>(hipStream_t, const int16_t *, const uint8_t *, const uint16_t *, const uint32_t *, uint32_t, uint64_t *,
+template void launch_pack_t<int16_t>(hipStream_t, const int16_t *, const uint8_t *, const uint16_t *, const void *, const uint32_t *, uint32_t, uint64_t *,
                                      uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, const PackTarget &,
                                      const Geometry &, uint32_t, uint32_t, uint32_t, uint32_t *);
 

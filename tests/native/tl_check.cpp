@@ -31,7 +31,7 @@ static uint64_t splitmix(uint64_t z) {
 }
 
 struct Event {
-    uint32_t ctx, val, off;
+    uint32_t ctx, val, off;  // off: offset in the tile | above << 12
 };
 
 // CPU model of one plane: events per tile, sorted by context (stable)
@@ -52,7 +52,7 @@ static void model_plane(const T *p, uint32_t W, uint32_t H, std::vector<std::vec
         Event e;
         e.ctx = (uint32_t)(Hh - L);
         e.val = px < L ? (uint32_t)(L - px - 1) : (uint32_t)(px - Hh - 1);
-        e.off = i % SORT_TILE;
+        e.off = (i % SORT_TILE) | (px > Hh ? 0x1000u : 0u);
         tiles[i / SORT_TILE].push_back(e);
     }
 }

@@ -168,8 +168,11 @@ __device__ __forceinline__ uint32_t field_of(int v, int16_t) { return ((uint32_t
 // The chain of a context is the sequence of its runs over the tiles (felics_chain.hip).
 // (six workgroups per CU is what the LDS allows -- five for Y / Co / Cg planes -- and the registers are held to that)
 // ------------------------------------------------------------------------------------------
+#ifndef FELICS_FRONT_WAVES
+#define FELICS_FRONT_WAVES 6  // (gray planes; what the LDS allows.  A/B builds: profiles/tools/variant.sh)
+#endif
 template <typename T, typename ET>
-__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 6 : 5))) __global__ __launch_bounds__(256) void k_front(
+__attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? FELICS_FRONT_WAVES : 5))) __global__ __launch_bounds__(256) void k_front(
     const T *__restrict__ planes, ET *__restrict__ ev, uint16_t *__restrict__ pix, uint32_t *__restrict__ runtab,
     uint32_t *__restrict__ tile_slots, uint32_t W, uint32_t npix, uint32_t ntiles, uint32_t tile_begin, uint32_t tile_end,
     uint32_t nplanes, uint32_t cap, uint32_t *__restrict__ flags, uint32_t mode) {
@@ -1445,8 +1448,11 @@ struct TSources {
     uint32_t cap, sort_ntiles;
 };
 
+#ifndef FELICS_PACK_WAVES
+#define FELICS_PACK_WAVES 6  // (what the LDS allows: 24.6 KB per workgroup of four waves; A/B builds: profiles/tools/variant.sh)
+#endif
 template <typename T>
-__attribute__((amdgpu_waves_per_eu(6))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_t(const T *__restrict__ planes, TSources ts, FusedArgs fa,
+__attribute__((amdgpu_waves_per_eu(FELICS_PACK_WAVES))) __global__ __launch_bounds__(PACK_THREADS) void k_pack_t(const T *__restrict__ planes, TSources ts, FusedArgs fa,
                                                                                                uint32_t sort_tile_begin, uint32_t pack_tile_end) {
     using ET = typename std::conditional<sizeof(T) == 1, uint8_t, uint16_t>::type;
     __shared__ alignas(16) uint32_t words[PACK_TILE + 4];  // the word of the event at pixel tile_first + j, 0 where there is none; [PACK_TILE]: dump
